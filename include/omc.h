@@ -1,0 +1,161 @@
+/* omc.h -- C ABI of the MI355X node-relaxation engine (libomc_hip.so).
+ *
+ * Drop-in boundary for the per-B&B-node hot path of OptimalMatrixCompletion.jl.  The reference has no FFI
+ * today; the seam is four plain-Julia call sites in the driver (OMC.jl = /root/reference/src/
+ * OptimalMatrixCompletion.jl):
+ *     relaxation            OMC.jl:747-754   -> matrix_completion_SDP_relaxation   OMC.jl:1431-1943
+ *     master feasibility    OMC.jl:814       -> matrix_completion_master_feasible  OMC.jl:1261-1277
+ *     altmin                OMC.jl:540-546, 875-881 -> alternating_minimization    OMC.jl:1979-2279
+ *     separation            OMC.jl:971-983   -> create_matrix_cut_child_nodes      OMC.jl:2466-2477
+ *     objective             OMC.jl:565, 925  -> evaluate_objective                 OMC.jl:2330-2359
+ * Each entry point below names the reference interface it replaces.  INTEGRATION.md shows the Julia
+ * `ccall` shim a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every matrix is COLUMN-MAJOR fp64 (Julia `Matrix{Float64}` layout);
+ *   - the caller owns every input and output array; the library keeps no host pointer after a call returns;
+ *   - device copies of A / mask live in the handle (they are constant for a whole B&B run, OMC.jl:470-471);
+ *   - return value: 0 = ok; < 0 = invalid argument (the reference's `error(...)` checks, OMC.jl:1455-1477,
+ *     2337-2348, 2433-2462); > 0 = HIP runtime error code.  Message via omc_last_error().  Nothing unwinds
+ *     across the boundary.
+ *   - safe to call from one host thread per handle; the batch entry point is the source of parallelism.
+ */
+#ifndef OMC_H
+#define OMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMC_VERSION 100
+
+/* termination status, mapped on the MOI statuses the driver branches on (OMC.jl:780-785, 809-812, 841) */
+#define OMC_OPTIMAL 0        /* MOI.OPTIMAL / LOCALLY_SOLVED: gap and feasibility tolerances met        */
+#define OMC_SLOW_PROGRESS 1  /* MOI.SLOW_PROGRESS: iteration cap reached, values available              */
+#define OMC_TIME_LIMIT 2     /* MOI.TIME_LIMIT: time limit reached, values available                    */
+#define OMC_INFEASIBLE 3     /* MOI.INFEASIBLE family: "feasible" = false (OMC.jl:1921-1935)            */
+
+/* disjunctive_cuts_type (OMC.jl:150, 1456) */
+#define OMC_CUT_LINEAR 0
+#define OMC_CUT_LINEAR2 1
+#define OMC_CUT_LINEAR3 2
+/* direction strings of a cut (OMC.jl:34, 2481-2491) */
+#define OMC_DIR_LEFT 0
+#define OMC_DIR_MIDDLE 1
+#define OMC_DIR_RIGHT 2
+#define OMC_DIR_INNER_LEFT 3
+#define OMC_DIR_INNER_RIGHT 4
+/* disjunctive_cuts_breakpoints (OMC.jl:151, 2466-2477) */
+#define OMC_SMALLEST_1_EIGVEC 1
+#define OMC_SMALLEST_2_EIGVEC 2
+
+/* error classes (negative return values) */
+#define OMC_ERR_INVALID_ENUM (-1)   /* OMC.jl:1456-1462, 2433-2446 */
+#define OMC_ERR_DIMENSION (-2)      /* OMC.jl:240-254, 1465-1477, 2337-2348 */
+#define OMC_ERR_ARGUMENT (-3)
+#define OMC_ERR_UNSUPPORTED (-4)    /* valid in the reference, not built yet (see DESIGN.md scope table) */
+#define OMC_ERR_NO_DEVICE (-5)
+
+typedef struct omc_instance omc_instance; /* opaque handle: device copies of A, mask, index lists, workspaces */
+
+/* solver parameters of the relaxation (all have defaults via omc_relax_params_default) */
+typedef struct omc_relax_params {
+  double eps_gap;      /* stop when objective - dual_bound <= eps_gap * max(1,|objective|)   (1e-6)  */
+  double eps_feas;     /* and cone residual <= eps_feas * sqrt(n+k)                          (1e-7)  */
+  int max_iters;       /* iteration cap -> OMC_SLOW_PROGRESS                                 (5000)  */
+  int check_every;     /* certificate evaluated every this many iterations                   (25)    */
+  double rho_scale;    /* penalty = rho_scale * gamma/2 ||A_Omega||^2 / (m (1+gamma k/n)^2)  (1.0)   */
+  double rho_f_ratio;  /* penalty of the per-column blocks relative to the cone blocks       (0.1)   */
+  double relax;        /* over-relaxation                                                    (1.6)   */
+  double time_limit;   /* seconds (OMC.jl:752, 1489)                                         (3600)  */
+  int reference_quirk_q1; /* 1: linear3/right piece exactly as OMC.jl:1675; 0: secant        (1)     */
+  int breakpoints;     /* OMC_SMALLEST_1_EIGVEC / _2_ : which separation vector to return    (1)     */
+  int stall_checks;    /* stop with OMC_SLOW_PROGRESS after this many stationary checks      (8)     */
+} omc_relax_params;
+
+void omc_relax_params_default(omc_relax_params* p);
+
+const char* omc_last_error(void);
+int omc_version(void);
+int omc_device_count(void);
+
+/* Upload (A, indices, gamma) once.  Replaces nothing in the reference (it passes A/indices to every call,
+ * OMC.jl:747-754); sizes are checked as OMC.jl:240-254 does.  `mask` is n*m bytes (0/1), column-major.   */
+int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mask, double gamma, int device,
+                        omc_instance** out);
+/* Same, with Julia's BitMatrix storage: packed UInt64 chunks, column-major bit order, LSB first. */
+int omc_instance_create_bits(int n, int m, int k, const double* A, const uint64_t* chunks, double gamma,
+                             int device, omc_instance** out);
+void omc_instance_destroy(omc_instance* h);
+
+/* ---- relaxation: matrix_completion_SDP_relaxation (OMC.jl:1431-1943), disjunctive mode -----------------
+ * B nodes at once.  Node b carries L[b] cuts; cuts of all nodes are concatenated:
+ *   cut_x    n      doubles per cut   (breakpoint vector,            OMC.jl:34 tuple element 1)
+ *   cut_Uhat n*k    doubles per cut   (parent's U, column-major,     tuple element 2)
+ *   cut_dir  k      int8 per cut      (OMC_DIR_* codes,              tuple element 3)
+ * U_lower / U_upper: n*k doubles per node, or NULL for the reference defaults (OMC.jl:1442-1449).
+ * Outputs (any matrix pointer may be NULL to skip the copy):
+ *   objective[b]   recomputed from primal values as OMC.jl:1880-1896 does
+ *   dual_bound[b]  certified lower bound on the relaxation optimum (reference quirk Q2: the reference uses
+ *                  the primal value as node bound; this engine returns both)
+ *   status[b], iters[b]
+ *   Y n*n, U n*k, X n*m, Theta m*m per node  (OMC.jl:1897-1900)
+ *   lambda_min[2*b..]: two smallest eigenvalues of U U' - Y      (OMC.jl:1274, 2467-2470)
+ *   breakpoint_x n per node: separation vector per params->breakpoints (OMC.jl:2466-2477), sign fixed so that
+ *                  its largest-magnitude entry is positive
+ *   solve_time[b]: seconds of device time attributed to the batch (same value for every node of the batch)
+ */
+int omc_relax_batch(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
+                    const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
+                    const double* U_upper, double* objective, double* dual_bound, int* status, int* iters,
+                    double* Y, double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x,
+                    double* solve_time);
+
+/* The same call split in three so that a caller (bench.py) can time the device-resident part alone:
+ * stage = host->device of the node descriptors, solve = kernels only, fetch = device->host of results.   */
+int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
+                    const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
+                    const double* U_upper);
+int omc_relax_solve(omc_instance* h);
+int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int* status, int* iters, double* Y,
+                    double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x,
+                    double* solve_time);
+
+/* ---- alternating_minimization (OMC.jl:1979-2279), disjunctive mode, B problems at once -----------------
+ * U_initial n*k per problem; cuts as above (only the per-cut bounds on v = U'x are imposed, OMC.jl:2047-2093).
+ * Outputs: U n*k, V k*m, converged, n_iters, objectives (max_iters doubles per problem, NaN padded).     */
+int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q1, const int* L,
+                     const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_initial,
+                     double eps, int max_iters, double time_limit, double* U, double* V, int* converged,
+                     int* n_iters, double* objectives, double* solve_time);
+
+/* ---- evaluate_objective (OMC.jl:2330-2359) for B matrices X (n*m each) --------------------------------- */
+int omc_evaluate_objective(omc_instance* h, int B, const double* X, double* objective);
+
+/* ---- separation / feasibility on caller-supplied (Y, U): OMC.jl:1272-1277 and 2466-2477 -----------------
+ * eigvals[2*b..] two smallest eigenvalues of U U' - Y; x n per problem; feasible[b] = eigvals[0] >= -1e-6 */
+int omc_separation_batch(omc_instance* h, int B, int breakpoints, const double* Y, const double* U,
+                         double* eigvals, double* x, int* feasible);
+
+/* ---- rounding glue: svd(M).U[:,1:k] of the symmetric PSD Y (OMC.jl:873) -------------------------------- */
+int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded);
+
+/* per-kernel accounting of the last omc_relax_solve: launches and HIP-event milliseconds per kernel class */
+#define OMC_KERNEL_COLPROX 0
+#define OMC_KERNEL_CONE 1
+#define OMC_KERNEL_GLOBAL 2
+#define OMC_KERNEL_CHECK 3
+#define OMC_KERNEL_SETUP 4
+#define OMC_KERNEL_SMALL 5
+#define OMC_KERNEL_NCLASS 6
+/* info[8]: solve seconds, total Jacobi sweeps of k_cone, rho, r_max, LDS flags (cone, global, small), R_max */
+int omc_last_solver_info(omc_instance* h, double* info);
+int omc_last_kernel_stats(omc_instance* h, int64_t* launches /*NCLASS*/, double* ms /*NCLASS*/,
+                          int64_t* units /*NCLASS*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMC_H */

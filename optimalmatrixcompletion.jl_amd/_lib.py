@@ -1,0 +1,78 @@
+"""ctypes binding of libomc_hip.so (the C ABI in include/omc.h).  No fallback: if the library is missing or no
+GPU is visible every compute entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libomc_hip.so")
+
+EXPORTS = [
+    "omc_relax_params_default", "omc_last_error", "omc_version", "omc_device_count", "omc_instance_create",
+    "omc_instance_create_bits", "omc_instance_destroy", "omc_relax_batch", "omc_relax_stage", "omc_relax_solve",
+    "omc_relax_fetch", "omc_altmin_batch", "omc_evaluate_objective", "omc_separation_batch", "omc_round_Y_batch",
+    "omc_last_kernel_stats", "omc_last_solver_info",
+]
+
+
+class RelaxParams(C.Structure):
+    _fields_ = [("eps_gap", C.c_double), ("eps_feas", C.c_double), ("max_iters", C.c_int), ("check_every", C.c_int),
+                ("rho_scale", C.c_double), ("rho_f_ratio", C.c_double), ("relax", C.c_double), ("time_limit", C.c_double),
+                ("reference_quirk_q1", C.c_int), ("breakpoints", C.c_int), ("stall_checks", C.c_int)]
+
+
+class OmcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libomc_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built: run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OmcError(-100, f"{LIB_PATH} not found: build it first (__graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int); vp = C.c_void_p
+    lib.omc_last_error.restype = C.c_char_p
+    lib.omc_version.restype = C.c_int
+    lib.omc_device_count.restype = C.c_int
+    lib.omc_relax_params_default.argtypes = [C.POINTER(RelaxParams)]
+    lib.omc_instance_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_double, C.c_int, C.POINTER(vp)]
+    lib.omc_instance_create_bits.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_double, C.c_int, C.POINTER(vp)]
+    lib.omc_instance_destroy.argtypes = [vp]
+    lib.omc_instance_destroy.restype = None
+    lib.omc_relax_batch.argtypes = [vp, C.c_int, C.POINTER(RelaxParams), C.c_int] + [vp] * 17
+    lib.omc_relax_stage.argtypes = [vp, C.c_int, C.POINTER(RelaxParams), C.c_int] + [vp] * 6
+    lib.omc_relax_solve.argtypes = [vp]
+    lib.omc_relax_fetch.argtypes = [vp] + [vp] * 11
+    lib.omc_altmin_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_double, C.c_int, C.c_double,
+                                     vp, vp, vp, vp, vp, vp]
+    lib.omc_evaluate_objective.argtypes = [vp, C.c_int, vp, vp]
+    lib.omc_separation_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.omc_round_Y_batch.argtypes = [vp, C.c_int, vp, vp]
+    lib.omc_last_kernel_stats.argtypes = [vp, vp, vp, vp]
+    lib.omc_last_solver_info.argtypes = [vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OmcError(rc, load().omc_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a, order="F"):
+    return np.require(np.asarray(a, dtype=np.float64), requirements=["ALIGNED"] + (["F_CONTIGUOUS"] if order == "F" else ["C_CONTIGUOUS"]))

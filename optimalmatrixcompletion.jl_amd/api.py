@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference's per-node interface (same names, argument meaning and error behaviour),
+backed by the HIP library.  Reference = /root/reference/src/OptimalMatrixCompletion.jl (OMC.jl).
+
+    Engine(A, indices, gamma, k)                  uploads (A, indices, gamma) once       (OMC.jl:470-471)
+    .matrix_completion_SDP_relaxation(nodes, ...) OMC.jl:1431-1943, a batch of nodes
+    .matrix_completion_master_feasible(Y, U)      OMC.jl:1261-1277
+    .breakpoint_vectors(Y, U, breakpoints)        OMC.jl:2466-2477
+    .evaluate_objective(X)                        OMC.jl:2330-2359
+    .alternating_minimization(U_initial, ...)     OMC.jl:1979-2279
+A node is the reference's BBNode reduced to what the relaxation reads: a list of cuts
+(breakpoint_vec, U_hat, directions) exactly as BBNodeDisjunctiveCuts.cuts holds them (OMC.jl:33-35).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RelaxParams, OmcError
+
+CUT_TYPES = {"linear": 0, "linear2": 1, "linear3": 2}
+DIR_CODES = {"left": 0, "middle": 1, "right": 2, "inner_left": 3, "inner_right": 4}
+BREAKPOINTS = {"smallest_1_eigvec": 1, "smallest_2_eigvec": 2}
+STATUS_NAMES = {0: "OPTIMAL", 1: "SLOW_PROGRESS", 2: "TIME_LIMIT", 3: "INFEASIBLE"}
+KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small"]
+
+
+def default_params(**kw) -> RelaxParams:
+    p = RelaxParams()
+    _lib.load().omc_relax_params_default(C.byref(p))
+    for k_, v in kw.items():
+        if not hasattr(p, k_):
+            raise TypeError(f"unknown relaxation parameter {k_!r}")
+        setattr(p, k_, v)
+    return p
+
+
+def _pack_cuts(nodes, n, k, cut_type):
+    if cut_type not in CUT_TYPES:
+        raise ValueError("Invalid input for disjunctive cuts type.\nDisjunctive cuts type must be either "
+                         f"\"linear\" or \"linear2\" or \"linear3\";\n{cut_type} supplied instead.")   # OMC.jl:1456-1462
+    L = np.array([len(c) for c in nodes], dtype=np.int32)
+    tot = int(L.sum())
+    cx = np.zeros((max(tot, 1), n)); cU = np.zeros((max(tot, 1), n * k)); cd = np.zeros((max(tot, 1), k), dtype=np.int8)
+    t = 0
+    for cuts in nodes:
+        for (x, Uh, dirs) in cuts:
+            x = np.asarray(x, float); Uh = np.asarray(Uh, float).reshape(n, k)
+            if x.shape != (n,) or len(dirs) != k:
+                raise ValueError("Dimension mismatch in cut (OMC.jl:34)")
+            cx[t] = x; cU[t] = Uh.ravel(order="F")
+            for j, d in enumerate(dirs):
+                cd[t, j] = DIR_CODES[d] if isinstance(d, str) else int(d)
+            t += 1
+    return L, cx, cU, cd
+
+
+class Engine:
+    """Device-resident instance + the four call sites of the reference driver."""
+
+    def __init__(self, A, indices, gamma, k, device=0):
+        A = np.asarray(A, dtype=np.float64); indices = np.asarray(indices)
+        if A.ndim != 2 or A.shape != indices.shape:
+            raise ValueError("Dimension mismatch.\nInput matrix A must have size (n, m);\nInput matrix indices must have size (n, m).")
+        self.n, self.m = A.shape
+        self.k = int(k); self.gamma = float(gamma)
+        self.A = np.asfortranarray(A); self.indices = indices.astype(bool)
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        mask = np.asfortranarray(self.indices.astype(np.uint8))
+        _lib.check(self._lib.omc_instance_create(self.n, self.m, self.k, _lib.ptr(self.A), _lib.ptr(mask), self.gamma,
+                                                 int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.omc_instance_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- relaxation ------------------------------------------------------------------------------------
+    def stage(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None):
+        n, k = self.n, self.k
+        L, cx, cU, cd = _pack_cuts(nodes, n, k, disjunctive_cuts_type)
+        p = params or default_params()
+        B = len(nodes)
+        lo = hi = None
+        if U_lower is not None:
+            lo = np.ascontiguousarray(np.stack([np.asfortranarray(u).ravel(order="F") for u in U_lower]))
+        if U_upper is not None:
+            hi = np.ascontiguousarray(np.stack([np.asfortranarray(u).ravel(order="F") for u in U_upper]))
+        self._keep = (L, cx, cU, cd, lo, hi, p)
+        _lib.check(self._lib.omc_relax_stage(self._h, B, C.byref(p), CUT_TYPES[disjunctive_cuts_type], _lib.ptr(L), _lib.ptr(cx),
+                                             _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(lo), _lib.ptr(hi)))
+        self._B = B
+
+    def solve(self):
+        _lib.check(self._lib.omc_relax_solve(self._h))
+
+    def fetch(self, want_Y=True, want_X=True, want_Theta=False):
+        B, n, m, k = self._B, self.n, self.m, self.k
+        obj = np.zeros(B); lb = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
+        Y = np.zeros((B, n * n)) if want_Y else None
+        U = np.zeros((B, n * k))
+        X = np.zeros((B, n * m)) if want_X else None
+        Th = np.zeros((B, m * m)) if want_Theta else None
+        lmin = np.zeros((B, 2)); bx = np.zeros((B, n)); tm = np.zeros(B)
+        _lib.check(self._lib.omc_relax_fetch(self._h, _lib.ptr(obj), _lib.ptr(lb), _lib.ptr(st), _lib.ptr(it), _lib.ptr(Y),
+                                             _lib.ptr(U), _lib.ptr(X), _lib.ptr(Th), _lib.ptr(lmin), _lib.ptr(bx), _lib.ptr(tm)))
+        out = []
+        for b in range(B):
+            r = {
+                "objective": float(obj[b]), "dual_bound": float(lb[b]), "termination_status": STATUS_NAMES[int(st[b])],
+                "status_code": int(st[b]), "feasible": int(st[b]) != 3, "iters": int(it[b]), "solve_time": float(tm[b]),
+                "U": U[b].reshape((n, k), order="F"), "lambda_min": lmin[b].copy(), "breakpoint_vec": bx[b].copy(),
+            }
+            if want_Y: r["Y"] = Y[b].reshape((n, n), order="F")
+            if want_X: r["X"] = X[b].reshape((n, m), order="F")
+            if want_Theta: r["Theta"] = Th[b].reshape((m, m), order="F")
+            out.append(r)
+        return out
+
+    def matrix_completion_SDP_relaxation(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None,
+                                         want_Y=True, want_X=True, want_Theta=False):
+        """Batch form of OMC.jl:1431-1943 (use_disjunctive_cuts = true, no Shor).  `nodes` = list of cut lists."""
+        self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper)
+        self.solve()
+        return self.fetch(want_Y, want_X, want_Theta)
+
+    def kernel_stats(self):
+        la = np.zeros(6, np.int64); ms = np.zeros(6); un = np.zeros(6, np.int64)
+        _lib.check(self._lib.omc_last_kernel_stats(self._h, _lib.ptr(la), _lib.ptr(ms), _lib.ptr(un)))
+        return {KERNEL_CLASSES[i]: dict(launches=int(la[i]), ms=float(ms[i]), units=int(un[i])) for i in range(6)}
+
+    def solver_info(self):
+        info = np.zeros(8)
+        _lib.check(self._lib.omc_last_solver_info(self._h, _lib.ptr(info)))
+        return dict(solve_seconds=info[0], jacobi_sweeps=int(info[1]), rho=info[2], r_max=int(info[3]), cone_lds=bool(info[4]),
+                    global_lds=bool(info[5]), small_lds=bool(info[6]), R_max=int(info[7]))
+
+    # ---- separation / feasibility ----------------------------------------------------------------------
+    def breakpoint_vectors(self, Ys, Us, disjunctive_cuts_breakpoints="smallest_1_eigvec"):
+        if disjunctive_cuts_breakpoints not in BREAKPOINTS:
+            raise ValueError("Invalid input for disjunctive cuts breakpoints.")                     # OMC.jl:2440-2446
+        B, n, k = len(Ys), self.n, self.k
+        Yb = np.ascontiguousarray(np.stack([np.asfortranarray(y, dtype=np.float64).ravel(order="F") for y in Ys]))
+        Ub = np.ascontiguousarray(np.stack([np.asfortranarray(np.asarray(u, float).reshape(n, k)).ravel(order="F") for u in Us]))
+        ev = np.zeros((B, 2)); x = np.zeros((B, n)); fe = np.zeros(B, np.int32)
+        _lib.check(self._lib.omc_separation_batch(self._h, B, BREAKPOINTS[disjunctive_cuts_breakpoints], _lib.ptr(Yb), _lib.ptr(Ub),
+                                                  _lib.ptr(ev), _lib.ptr(x), _lib.ptr(fe)))
+        return x, ev, fe.astype(bool)
+
+    def matrix_completion_master_feasible(self, Y, U):
+        """OMC.jl:1261-1277 (disjunctive branch): lambda_min(U U' - Y) >= -1e-6."""
+        _, ev, fe = self.breakpoint_vectors([Y], [U])
+        return bool(fe[0])
+
+    # ---- objective -------------------------------------------------------------------------------------
+    def evaluate_objective(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        single = X.ndim == 2
+        Xs = [X] if single else list(X)
+        for x in Xs:
+            if x.shape != (self.n, self.m):
+                raise ValueError("Dimension mismatch.\nInput matrix X must have size (n, m).")          # OMC.jl:2337-2348
+        Xb = np.ascontiguousarray(np.stack([np.asfortranarray(x).ravel(order="F") for x in Xs]))
+        out = np.zeros(len(Xs))
+        _lib.check(self._lib.omc_evaluate_objective(self._h, len(Xs), _lib.ptr(Xb), _lib.ptr(out)))
+        return float(out[0]) if single else out

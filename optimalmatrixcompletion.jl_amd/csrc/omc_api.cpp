@@ -1,0 +1,623 @@
+// omc_api.cpp -- host side of libomc_hip.so: the C ABI declared in include/omc.h.
+//
+// Mirrors the call sites of the reference driver (OMC.jl = /root/reference/src/OptimalMatrixCompletion.jl):
+//   omc_relax_*            <- matrix_completion_SDP_relaxation  OMC.jl:1431-1943 (called at 747-754)
+//   omc_separation_batch   <- eigs(U U' - Y) at OMC.jl:1274 and 2466-2477
+//   omc_evaluate_objective <- evaluate_objective OMC.jl:2330-2359
+//   omc_altmin_batch       <- alternating_minimization OMC.jl:1979-2279
+// Argument checks reproduce the reference's `error(...)` conditions and return negative codes instead of
+// throwing.  No torch types, no host pointer retained after return.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <chrono>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "omc.h"
+#include "omc_device.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                         \
+  do {                                                                                                    \
+    hipError_t e_ = (x);                                                                                  \
+    if (e_ != hipSuccess) {                                                                               \
+      g_err = std::string(#x) + ": " + hipGetErrorString(e_);                                             \
+      return (int)e_ > 0 ? (int)e_ : 999;                                                                 \
+    }                                                                                                     \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return (int)e; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() { return (T*)p; }
+};
+
+struct omc_instance {
+  int n = 0, m = 0, k = 0, device = 0, nnz = 0, cmax = 0;
+  double gamma = 0, sumA2 = 0;
+  std::vector<int> col_ptr, col_idx; std::vector<double> col_val;
+  std::vector<double> A; std::vector<uint8_t> mask;
+  std::vector<double> Ncnt;
+  hipStream_t stream = nullptr;
+  DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY;
+  // batch workspace
+  DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
+  DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
+  DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin;
+  OmcWS ws{};
+  omc_relax_params params{};
+  bool staged = false;
+  int cone_use_lds = 0, glob_use_lds = 0, small_use_lds = 0; size_t cone_lds = 0, glob_lds = 0, small_lds = 0;
+  double last_solve_seconds = 0; long long total_sweeps = 0;
+  // kernel stats
+  int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
+  std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+  std::vector<int> ev_class;
+};
+
+extern "C" {
+
+const char* omc_last_error(void) { return g_err.c_str(); }
+int omc_version(void) { return OMC_VERSION; }
+int omc_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+void omc_relax_params_default(omc_relax_params* p) {
+  p->eps_gap = 1e-6; p->eps_feas = 1e-7; p->max_iters = 5000; p->check_every = 25;
+  p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
+  p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
+}
+
+static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
+  int rc = b.ensure(bytes ? bytes : 8);
+  if (rc) return rc;
+  if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mask, double gamma, int device,
+                        omc_instance** out) {
+  if (!out) return fail(OMC_ERR_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (!A || !mask) return fail(OMC_ERR_ARGUMENT, "A / mask is NULL");
+  if (n <= 0 || m <= 0) return fail(OMC_ERR_DIMENSION, "Dimension mismatch: A must have size (n, m) (OMC.jl:240-246)");
+  if (!(n <= m)) return fail(OMC_ERR_DIMENSION, "Input matrix A must have size (n, m) with n <= m (OMC.jl:249-254)");
+  if (k < 1 || k > n) return fail(OMC_ERR_ARGUMENT, "rank k must satisfy 1 <= k <= n");
+  if (k > 8) return fail(OMC_ERR_UNSUPPORTED, "k > 8 is not supported by this build");
+  if (!(gamma > 0.0)) return fail(OMC_ERR_ARGUMENT, "gamma must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(OMC_ERR_NO_DEVICE, "no HIP device visible: the HIP path is the product, there is no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(OMC_ERR_ARGUMENT, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  omc_instance* h = new omc_instance();
+  h->n = n; h->m = m; h->k = k; h->gamma = gamma; h->device = device;
+  h->A.assign(A, A + (size_t)n * m);
+  h->mask.resize((size_t)n * m);
+  for (size_t e = 0; e < (size_t)n * m; ++e) h->mask[e] = mask[e] ? 1 : 0;
+  h->col_ptr.assign(m + 1, 0);
+  for (int j = 0; j < m; ++j) {
+    int c = 0;
+    for (int i = 0; i < n; ++i)
+      if (h->mask[(size_t)j * n + i]) { h->col_idx.push_back(i); h->col_val.push_back(A[(size_t)j * n + i]); ++c; }
+    h->col_ptr[j + 1] = h->col_ptr[j] + c;
+    h->cmax = std::max(h->cmax, c);
+  }
+  h->nnz = h->col_ptr[m];
+  h->sumA2 = 0;
+  for (double v : h->col_val) h->sumA2 += v * v;
+  h->Ncnt.assign((size_t)n * n, 0.0);
+  for (int j = 0; j < m; ++j)
+    for (int p = h->col_ptr[j]; p < h->col_ptr[j + 1]; ++p)
+      for (int q = h->col_ptr[j]; q < h->col_ptr[j + 1]; ++q)
+        h->Ncnt[(size_t)h->col_idx[q] * n + h->col_idx[p]] += 1.0;
+  HIPCHK(hipStreamCreate(&h->stream));
+  int rc = 0;
+  if ((rc = upload(h->dA, h->A.data(), sizeof(double) * n * m, h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->dmask, h->mask.data(), (size_t)n * m, h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->dcol_ptr, h->col_ptr.data(), sizeof(int) * (m + 1), h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->dcol_idx, h->col_idx.data(), sizeof(int) * h->nnz, h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->dcol_val, h->col_val.data(), sizeof(double) * h->nnz, h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->dNcnt, h->Ncnt.data(), sizeof(double) * n * n, h->stream))) { delete h; return rc; }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int lrc = omc_set_max_lds();
+  if (lrc) { delete h; return fail(lrc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); }
+  omc_relax_params_default(&h->params);
+  *out = h;
+  return 0;
+}
+
+int omc_instance_create_bits(int n, int m, int k, const double* A, const uint64_t* chunks, double gamma, int device,
+                             omc_instance** out) {
+  if (!chunks) return fail(OMC_ERR_ARGUMENT, "chunks is NULL");
+  if (n <= 0 || m <= 0) return fail(OMC_ERR_DIMENSION, "Dimension mismatch (OMC.jl:240-246)");
+  std::vector<uint8_t> mask((size_t)n * m);
+  for (size_t e = 0; e < (size_t)n * m; ++e) mask[e] = (uint8_t)((chunks[e >> 6] >> (e & 63)) & 1ull);
+  return omc_instance_create(n, m, k, A, mask.data(), gamma, device, out);
+}
+
+void omc_instance_destroy(omc_instance* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  DevBuf* all[] = {&h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
+                   &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
+                   &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
+                   &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
+                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin};
+  for (DevBuf* b : all) b->release();
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// piece table of the disjunctive cuts (OMC.jl:1580-1678): lo <= v <= hi, g(v) = slope*v + icpt
+static int cut_piece(int cut_type, int dir, double vhat, int q1, double* lo, double* hi, double* slope, double* icpt) {
+  const double a = fabs(vhat);
+  if (cut_type == OMC_CUT_LINEAR) {
+    if (dir == OMC_DIR_LEFT) { *lo = -1; *hi = vhat; *slope = vhat - 1; *icpt = vhat; return 0; }      // 1582-1591
+    if (dir == OMC_DIR_RIGHT) { *lo = vhat; *hi = 1; *slope = vhat + 1; *icpt = -vhat; return 0; }     // 1592-1601
+  } else if (cut_type == OMC_CUT_LINEAR2) {
+    if (dir == OMC_DIR_LEFT) { *lo = -1; *hi = -a; *slope = -(1 + a); *icpt = -a; return 0; }          // 1604-1613
+    if (dir == OMC_DIR_MIDDLE) { *lo = -a; *hi = a; *slope = 0; *icpt = vhat * vhat; return 0; }       // 1614-1623
+    if (dir == OMC_DIR_RIGHT) { *lo = a; *hi = 1; *slope = 1 + a; *icpt = -a; return 0; }              // 1624-1633
+  } else if (cut_type == OMC_CUT_LINEAR3) {
+    if (dir == OMC_DIR_LEFT) { *lo = -1; *hi = -a; *slope = -(1 + a); *icpt = -a; return 0; }          // 1636-1645
+    if (dir == OMC_DIR_INNER_LEFT) { *lo = -a; *hi = 0; *slope = -a; *icpt = 0; return 0; }            // 1646-1655
+    if (dir == OMC_DIR_INNER_RIGHT) { *lo = 0; *hi = a; *slope = a; *icpt = 0; return 0; }             // 1656-1665
+    if (dir == OMC_DIR_RIGHT) {                                                                        // 1666-1675
+      *lo = a; *hi = 1;
+      if (q1) { *slope = a; *icpt = 0; } else { *slope = 1 + a; *icpt = -a; }
+      return 0;
+    }
+  }
+  return -1;
+}
+
+static hipEvent_t next_event(omc_instance* h) {
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t e; (void)hipEventCreate(&e); h->ev_pool.push_back(e);
+  }
+  return h->ev_pool[h->ev_used++];
+}
+#define TIMED(cls, units_, call)                     \
+  do {                                               \
+    hipEvent_t e0_ = next_event(h), e1_ = next_event(h); \
+    (void)hipEventRecord(e0_, h->stream);            \
+    call;                                            \
+    (void)hipEventRecord(e1_, h->stream);            \
+    h->ev_class.push_back(cls);                      \
+    h->launches[cls] += 1; h->units[cls] += (units_); \
+  } while (0)
+
+int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
+                    const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
+                    const double* U_upper) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (B <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
+  if (cut_type != OMC_CUT_LINEAR && cut_type != OMC_CUT_LINEAR2 && cut_type != OMC_CUT_LINEAR3)
+    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type: must be linear, linear2 or linear3 (OMC.jl:1456-1462)");
+  HIPCHK(hipSetDevice(h->device));
+  h->staged = false;
+  if (params) h->params = *params; else omc_relax_params_default(&h->params);
+  const omc_relax_params& P = h->params;
+  if (P.breakpoints != OMC_SMALLEST_1_EIGVEC && P.breakpoints != OMC_SMALLEST_2_EIGVEC)
+    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts breakpoints (OMC.jl:2440-2446)");
+  const int n = h->n, m = h->m, k = h->k, N = n + k;
+  // ---- rows (host) -----------------------------------------------------------------------------------
+  int Lmax = 0; long Ltot = 0;
+  for (int b = 0; b < B; ++b) {
+    int Lb = L ? L[b] : 0;
+    if (Lb < 0) return fail(OMC_ERR_ARGUMENT, "negative cut count");
+    Lmax = std::max(Lmax, Lb); Ltot += Lb;
+  }
+  if (Ltot > 0 && (!cut_x || !cut_Uhat || !cut_dir)) return fail(OMC_ERR_ARGUMENT, "cut arrays are NULL but L > 0");
+  // box rows: entries whose bound is not implied by ||U_j|| <= 1 (OMC.jl:1561, defaults 1442-1449)
+  std::vector<std::vector<int>> rk(B), rc(B), rbi(B), rbj(B);
+  std::vector<std::vector<double>> rcoef(B), rrhs(B);
+  int Rmax = 0;
+  long cutbase = 0;
+  for (int b = 0; b < B; ++b) {
+    auto add = [&](int kind, int cut, int bi, int bj, const double* coef, double rhs) {
+      rk[b].push_back(kind); rc[b].push_back(cut); rbi[b].push_back(bi); rbj[b].push_back(bj);
+      for (int j = 0; j < k; ++j) rcoef[b].push_back(coef ? coef[j] : 0.0);
+      rrhs[b].push_back(rhs);
+    };
+    add(ROW_TRACE, -1, -1, -1, nullptr, (double)k);                                 // OMC.jl:1558
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < n; ++i) {
+        double lo = U_lower ? U_lower[(size_t)b * n * k + (size_t)j * n + i] : ((i >= n - k + j) ? 0.0 : -1.0);
+        double hi = U_upper ? U_upper[(size_t)b * n * k + (size_t)j * n + i] : 1.0;
+        if (lo > hi) return fail(OMC_ERR_ARGUMENT, "U_lower > U_upper");
+        double cf[8] = {0};
+        if (lo > -1.0) { cf[0] = -1.0; add(ROW_BOX, -1, i, j, cf, -lo); }
+        if (hi < 1.0) { cf[0] = 1.0; add(ROW_BOX, -1, i, j, cf, hi); }
+      }
+    const int Lb = L ? L[b] : 0;
+    for (int l = 0; l < Lb; ++l) {
+      const double* x = cut_x + (size_t)(cutbase + l) * n;
+      const double* Uh = cut_Uhat + (size_t)(cutbase + l) * n * k;
+      const int8_t* dr = cut_dir + (size_t)(cutbase + l) * k;
+      double slope[8], icsum = 0.0;
+      for (int j = 0; j < k; ++j) {
+        double vhat = 0.0;                                                         // OMC.jl:1577
+        for (int i = 0; i < n; ++i) vhat += Uh[(size_t)j * n + i] * x[i];
+        double lo, hi, sl, ic;
+        if (cut_piece(cut_type, dr[j], vhat, P.reference_quirk_q1, &lo, &hi, &sl, &ic))
+          return fail(OMC_ERR_INVALID_ENUM, "direction code invalid for this cut type (OMC.jl:1580-1678)");
+        slope[j] = -sl; icsum += ic;
+        double cf[8] = {0};
+        cf[j] = 1.0; add(ROW_BOUND, l, -1, j, cf, hi);                              // v_j <= hi
+        cf[j] = -1.0; add(ROW_BOUND, l, -1, j, cf, -lo);                            // -v_j <= -lo
+      }
+      add(ROW_CUT, l, -1, -1, slope, icsum);                                        // OMC.jl:1680-1683
+    }
+    cutbase += Lb;
+    Rmax = std::max(Rmax, (int)rk[b].size());
+  }
+  // ---- subspace of the U functionals: modified Gram-Schmidt (twice) over the row vectors in row order ------
+  std::vector<std::vector<double>> Qn(B);
+  std::vector<int> rrv(B, 0);
+  int rmax = 1;
+  cutbase = 0;
+  for (int b = 0; b < B; ++b) {
+    std::vector<double>& Qv = Qn[b];
+    int r = 0;
+    std::vector<double> v(n);
+    const int Lb = L ? L[b] : 0;
+    for (size_t rw = 0; rw < rk[b].size(); ++rw) {
+      const int kind = rk[b][rw];
+      if (kind == ROW_TRACE) continue;
+      for (int j = 0; j < k; ++j) {
+        const double cf = rcoef[b][rw * k + j];
+        bool nz = false;
+        if (kind == ROW_BOX) {
+          if (j != rbj[b][rw]) continue;
+          std::fill(v.begin(), v.end(), 0.0); v[rbi[b][rw]] = rcoef[b][rw * k] > 0 ? 1.0 : -1.0; nz = true;
+        } else if (cf != 0.0) {
+          const double* x = cut_x + (size_t)(cutbase + rc[b][rw]) * n;
+          double nx = 0.0;
+          for (int i = 0; i < n; ++i) nx += x[i] * x[i];
+          nx = sqrt(nx) * fabs(cf);
+          if (nx > 0) { for (int i = 0; i < n; ++i) v[i] = cf * x[i] / nx; nz = true; }
+        }
+        if (!nz) continue;
+        for (int pass = 0; pass < 2; ++pass)
+          for (int a = 0; a < r; ++a) {
+            double d = 0.0;
+            for (int i = 0; i < n; ++i) d += Qv[(size_t)a * n + i] * v[i];
+            for (int i = 0; i < n; ++i) v[i] -= d * Qv[(size_t)a * n + i];
+          }
+        double nv = 0.0;
+        for (int i = 0; i < n; ++i) nv += v[i] * v[i];
+        nv = sqrt(nv);
+        if (nv > 1e-10 && r < n) {
+          Qv.resize((size_t)(r + 1) * n);
+          for (int i = 0; i < n; ++i) Qv[(size_t)r * n + i] = v[i] / nv;
+          ++r;
+        }
+      }
+    }
+    rrv[b] = r; rmax = std::max(rmax, r);
+    cutbase += Lb;
+  }
+  // ---- workspace -------------------------------------------------------------------------------------
+  OmcWS& w = h->ws;
+  memset(&w, 0, sizeof(w));
+  w.B = B; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
+  w.breakpoints = P.breakpoints; w.stall_checks = P.stall_checks > 0 ? P.stall_checks : 1000000;
+  w.gamma = h->gamma; w.sumA2 = h->sumA2;
+  {
+    const double sh = 1.0 + h->gamma * (double)k / (double)n;
+    w.rho = P.rho_scale * 0.5 * h->gamma * h->sumA2 / ((double)m * sh * sh);
+  }
+  if (!(w.rho > 0.0)) w.rho = 1.0;
+  w.rho_f = w.rho * P.rho_f_ratio;
+  w.relax = P.relax; w.eps_gap = P.eps_gap; w.eps_feas = P.eps_feas;
+  std::vector<double> wY((size_t)n * n);
+  for (size_t e = 0; e < (size_t)n * n; ++e) wY[e] = P.rho_f_ratio * h->Ncnt[e] + 2.0;
+  int rc_ = 0;
+  if ((rc_ = upload(h->dwY, wY.data(), sizeof(double) * n * n, h->stream))) return rc_;
+  w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
+  w.Ncnt = h->dNcnt.as<double>(); w.wY1 = h->dwY.as<double>();
+#define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)
+  const size_t sB = (size_t)B;
+  ENS(h->bY, sB * n * n * 8); ENS(h->bYp, sB * n * n * 8); ENS(h->bU, sB * n * k * 8);
+  ENS(h->bD1, sB * n * n * 8); ENS(h->bD3, sB * n * n * 8); ENS(h->bW1, sB * n * n * 8); ENS(h->bE3, sB * n * n * 8);
+  ENS(h->bdS, sB * rmax * rmax * 8);
+  ENS(h->bsm, sB * ((size_t)4 * rmax * k + 3 * k * k) * 8);
+  ENS(h->balpha, sB * h->nnz * 8); ENS(h->balphaX, sB * h->nnz * 8); ENS(h->bsval, sB * m * 8);
+  ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8);
+  ENS(h->bG, sB * Rmax * Rmax * 8); ENS(h->blam, sB * Rmax * 8);
+  ENS(h->bscal, sB * 14 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 5 * sizeof(int));
+  w.Y = h->bY.as<double>(); w.Yp = h->bYp.as<double>(); w.U = h->bU.as<double>();
+  w.D1 = h->bD1.as<double>(); w.D3 = h->bD3.as<double>(); w.W1 = h->bW1.as<double>(); w.E3 = h->bE3.as<double>();
+  w.dS = h->bdS.as<double>();
+  {
+    double* sm = h->bsm.as<double>();
+    const size_t vk = sB * rmax * k, tk = sB * k * k;
+    w.Vt = sm; w.D3V = sm + vk; w.W3V = sm + 2 * vk; w.Q3V = sm + 3 * vk;
+    w.D3T = sm + 4 * vk; w.W3T = sm + 4 * vk + tk; w.Q3T = sm + 4 * vk + 2 * tk;
+  }
+  w.alpha = h->balpha.as<double>(); w.alphaX = h->balphaX.as<double>(); w.sval = h->bsval.as<double>();
+  w.Mchk = h->bMchk.as<double>(); w.chk_scratch = h->bchk.as<double>(); w.G = h->bG.as<double>(); w.lam = h->blam.as<double>();
+  double* sc = h->bscal.as<double>();
+  w.obj = sc; w.objout = sc + sB; w.lb = sc + 2 * sB; w.c0 = sc + 3 * sB; w.evsum = sc + 4 * sB; w.cpen = sc + 5 * sB;
+  w.cst = sc + 6 * sB; w.rp = sc + 7 * sB; w.rd = sc + 8 * sB; w.lmin = sc + 9 * sB;  // lmin uses 2B (slots 9,10)
+  w.objprev = sc + 11 * sB; w.lbprev = sc + 12 * sB;
+  w.bx = h->bbx.as<double>();
+  int* ip = h->bint.as<int>();
+  w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB;
+  // Q upload
+  {
+    std::vector<double> hQ(sB * n * rmax, 0.0);
+    for (int b = 0; b < B; ++b) memcpy(&hQ[(size_t)b * n * rmax], Qn[b].data(), sizeof(double) * Qn[b].size());
+    if ((rc_ = upload(h->bQb, hQ.data(), sizeof(double) * hQ.size(), h->stream))) return rc_;
+    if ((rc_ = upload(h->brr, rrv.data(), sizeof(int) * B, h->stream))) return rc_;
+    w.Qb = h->bQb.as<double>(); w.rr = h->brr.as<int>();
+  }
+  // rows upload (padded to Rmax)
+  std::vector<int> hR(B), hk(sB * Rmax, 0), hc(sB * Rmax, 0), hbi(sB * Rmax, 0), hbj(sB * Rmax, 0);
+  std::vector<double> hcoef(sB * Rmax * k, 0.0), hrhs(sB * Rmax, 0.0), hx(sB * w.Lmax * n, 0.0);
+  cutbase = 0;
+  for (int b = 0; b < B; ++b) {
+    hR[b] = (int)rk[b].size();
+    for (int r = 0; r < hR[b]; ++r) {
+      hk[(size_t)b * Rmax + r] = rk[b][r]; hc[(size_t)b * Rmax + r] = rc[b][r];
+      hbi[(size_t)b * Rmax + r] = rbi[b][r]; hbj[(size_t)b * Rmax + r] = rbj[b][r];
+      hrhs[(size_t)b * Rmax + r] = rrhs[b][r];
+      for (int j = 0; j < k; ++j) hcoef[((size_t)b * Rmax + r) * k + j] = rcoef[b][(size_t)r * k + j];
+    }
+    const int Lb = L ? L[b] : 0;
+    for (int l = 0; l < Lb; ++l)
+      memcpy(&hx[((size_t)b * w.Lmax + l) * n], cut_x + (size_t)(cutbase + l) * n, sizeof(double) * n);
+    cutbase += Lb;
+  }
+  if ((rc_ = upload(h->bR, hR.data(), sizeof(int) * B, h->stream))) return rc_;
+  if ((rc_ = upload(h->brkind, hk.data(), sizeof(int) * hk.size(), h->stream))) return rc_;
+  if ((rc_ = upload(h->brcut, hc.data(), sizeof(int) * hc.size(), h->stream))) return rc_;
+  if ((rc_ = upload(h->brbi, hbi.data(), sizeof(int) * hbi.size(), h->stream))) return rc_;
+  if ((rc_ = upload(h->brbj, hbj.data(), sizeof(int) * hbj.size(), h->stream))) return rc_;
+  if ((rc_ = upload(h->brcoef, hcoef.data(), sizeof(double) * hcoef.size(), h->stream))) return rc_;
+  if ((rc_ = upload(h->brrhs, hrhs.data(), sizeof(double) * hrhs.size(), h->stream))) return rc_;
+  if ((rc_ = upload(h->bcutx, hx.data(), sizeof(double) * hx.size(), h->stream))) return rc_;
+  w.R = h->bR.as<int>(); w.rkind = h->brkind.as<int>(); w.rcut = h->brcut.as<int>(); w.rbi = h->brbi.as<int>();
+  w.rbj = h->brbj.as<int>(); w.rcoef = h->brcoef.as<double>(); w.rrhs = h->brrhs.as<double>(); w.cutx = h->bcutx.as<double>();
+  // LDS / scratch decisions
+  {
+    const int c_lds = std::min(h->cmax, 64);
+    w.cp_lds_c = c_lds;
+    w.cp_lds_doubles = c_lds * c_lds + 5 * c_lds + 8;
+    if ((size_t)4 * w.cp_lds_doubles * 8 > OMC_MAX_DYN_LDS) { w.cp_lds_c = 48; w.cp_lds_doubles = 48 * 48 + 5 * 48 + 8; }
+    if (h->cmax > w.cp_lds_c) {
+      w.cp_scratch_stride = (size_t)h->cmax * h->cmax + 5 * (size_t)h->cmax + 8;
+      ENS(h->bcp, sB * m * w.cp_scratch_stride * 8);
+      w.cp_scratch = h->bcp.as<double>();
+    }
+    auto cone_bytes = [](int Nn) { int Np = (Nn + 1) & ~1; int ld = Np | 1; return ((size_t)Np * ld + 2 * Np) * 8 + (size_t)Np * 4 + 16; };
+    h->cone_lds = cone_bytes(n);
+    h->cone_use_lds = h->cone_lds <= OMC_MAX_DYN_LDS;
+    if (!h->cone_use_lds) {
+      w.cone_scratch_stride = h->cone_lds / 8 + 8;
+      ENS(h->bcone, sB * w.cone_scratch_stride * 8);
+      w.cone_scratch = h->bcone.as<double>();
+    }
+    h->glob_lds = ((size_t)n * n + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8;
+    h->glob_use_lds = h->glob_lds + 12 * 1024 <= OMC_MAX_DYN_LDS;
+    if (!h->glob_use_lds) {
+      w.glob_scratch_stride = h->glob_lds / 8 + 8;
+      ENS(h->bglob, sB * w.glob_scratch_stride * 8);
+      w.glob_scratch = h->bglob.as<double>();
+    }
+    {
+      const int N3 = rmax + k; const int Npm = (N3 + 1) & ~1, ldm = Npm | 1;
+      h->small_lds = ((size_t)n * rmax + (size_t)N3 * N3 + (size_t)Npm * ldm + 2 * Npm + (size_t)rmax * k + 8) * 8 + (size_t)(Npm + 2) * 4 + 16;
+      h->small_use_lds = h->small_lds + 1024 <= OMC_MAX_DYN_LDS;
+      if (!h->small_use_lds) {
+        w.small_scratch_stride = h->small_lds / 8 + 8;
+        ENS(h->bsmall, sB * w.small_scratch_stride * 8);
+        w.small_scratch = h->bsmall.as<double>();
+      }
+    }
+  }
+  HIPCHK(hipMemsetAsync(w.sweeps, 0, sizeof(int) * B, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->staged = true;
+  return 0;
+}
+
+static int finish_events(omc_instance* h) {
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float msv = 0.f;
+    if (hipEventElapsedTime(&msv, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) h->ms[h->ev_class[i / 2]] += msv;
+  }
+  h->ev_used = 0; h->ev_class.clear();
+  return 0;
+}
+
+int omc_relax_solve(omc_instance* h) {
+  if (!h || !h->staged) return fail(OMC_ERR_ARGUMENT, "omc_relax_solve: nothing staged");
+  HIPCHK(hipSetDevice(h->device));
+  const OmcWS& w = h->ws;
+  const omc_relax_params& P = h->params;
+  for (int c = 0; c < OMC_KERNEL_NCLASS; ++c) { h->launches[c] = 0; h->ms[c] = 0; h->units[c] = 0; }
+  h->ev_used = 0; h->ev_class.clear();
+  auto t0 = std::chrono::steady_clock::now();
+  hipStream_t s = h->stream;
+  const int B = w.B;
+  TIMED(OMC_KERNEL_SETUP, B, omc_launch_setup(&w, s));
+  std::vector<int> done(B, 0);
+  int nactive = B;
+  int it = 0;
+  const int check = std::max(1, P.check_every);
+  bool timed_out = false;
+  while (it < P.max_iters && nactive > 0) {
+    ++it;
+    TIMED(OMC_KERNEL_COLPROX, (int64_t)nactive * w.m, omc_launch_colprox(&w, 0, s));
+    TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone(&w, CONE_CLIP01, h->cone_use_lds, h->cone_lds, s));
+    TIMED(OMC_KERNEL_SMALL, nactive, omc_launch_small(&w, SMALL_PROJ, h->small_use_lds, h->small_lds, s));
+    TIMED(OMC_KERNEL_GLOBAL, nactive, omc_launch_global(&w, h->glob_use_lds, h->glob_lds, s));
+    const bool last = (it == P.max_iters);
+    if (it % check == 0 || last) {
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      timed_out = el > P.time_limit;
+      TIMED(OMC_KERNEL_CHECK, nactive, {
+        omc_launch_check_zero(&w, s);
+        omc_launch_colprox(&w, 1, s);
+        omc_launch_check_build(&w, s);
+        omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
+        omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : (last ? OMC_ST_SLOW : 0), s);
+      });
+      HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      nactive = 0;
+      for (int b = 0; b < B; ++b) nactive += done[b] ? 0 : 1;
+      if (timed_out) break;
+    }
+  }
+  // separation vector of every node on its final (Y, U)  (OMC.jl:2466-2477)
+  TIMED(OMC_KERNEL_CHECK, B, {
+    omc_launch_small(&w, SMALL_RECOVER, h->small_use_lds, h->small_lds, s);   // a U with U U' <= Y and the same Q'U
+    omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, s);
+  });
+  {
+    std::vector<int> sw(B);
+    HIPCHK(hipMemcpyAsync(sw.data(), w.sweeps, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->total_sweeps = 0; for (int v : sw) h->total_sweeps += v;
+  }
+  HIPCHK(hipGetLastError());
+  finish_events(h);
+  h->last_solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int* status, int* iters, double* Y,
+                    double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x, double* solve_time) {
+  if (!h || !h->staged) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch: nothing staged");
+  HIPCHK(hipSetDevice(h->device));
+  const OmcWS& w = h->ws;
+  const size_t B = w.B, n = w.n, m = w.m, k = w.k;
+  hipStream_t s = h->stream;
+  if (objective) HIPCHK(hipMemcpyAsync(objective, w.objout, 8 * B, hipMemcpyDeviceToHost, s));
+  if (dual_bound) HIPCHK(hipMemcpyAsync(dual_bound, w.lb, 8 * B, hipMemcpyDeviceToHost, s));
+  if (status) HIPCHK(hipMemcpyAsync(status, w.status, 4 * B, hipMemcpyDeviceToHost, s));
+  if (iters) HIPCHK(hipMemcpyAsync(iters, w.iters, 4 * B, hipMemcpyDeviceToHost, s));
+  if (Y) HIPCHK(hipMemcpyAsync(Y, w.Y, 8 * B * n * n, hipMemcpyDeviceToHost, s));
+  if (U) HIPCHK(hipMemcpyAsync(U, w.U, 8 * B * n * k, hipMemcpyDeviceToHost, s));
+  if (lambda_min) HIPCHK(hipMemcpyAsync(lambda_min, w.lmin, 8 * 2 * B, hipMemcpyDeviceToHost, s));
+  if (breakpoint_x) HIPCHK(hipMemcpyAsync(breakpoint_x, w.bx, 8 * B * n, hipMemcpyDeviceToHost, s));
+  if (X || Theta) {
+    int r_ = h->bXout.ensure(8 * B * n * m); if (r_) return r_;
+    omc_launch_make_X(&w, h->bXout.as<double>(), s);
+    if (X) HIPCHK(hipMemcpyAsync(X, h->bXout.p, 8 * B * n * m, hipMemcpyDeviceToHost, s));
+    if (Theta) {
+      r_ = h->bThout.ensure(8 * B * m * m); if (r_) return r_;
+      omc_launch_make_Theta(&w, h->bXout.as<double>(), h->bThout.as<double>(), s);
+      HIPCHK(hipMemcpyAsync(Theta, h->bThout.p, 8 * B * m * m, hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  if (solve_time) for (size_t b = 0; b < B; ++b) solve_time[b] = h->last_solve_seconds;
+  // a status still SLOW/TIME here has values (OMC.jl:1871-1877): feasible = true for every node
+  return 0;
+}
+
+int omc_relax_batch(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
+                    const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
+                    const double* U_upper, double* objective, double* dual_bound, int* status, int* iters, double* Y,
+                    double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x, double* solve_time) {
+  int rc = omc_relax_stage(h, B, params, cut_type, L, cut_x, cut_Uhat, cut_dir, U_lower, U_upper);
+  if (rc) return rc;
+  rc = omc_relax_solve(h);
+  if (rc) return rc;
+  return omc_relax_fetch(h, objective, dual_bound, status, iters, Y, U, X, Theta, lambda_min, breakpoint_x, solve_time);
+}
+
+int omc_evaluate_objective(omc_instance* h, int B, const double* X, double* objective) {
+  if (!h || !X || !objective) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (B <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t n = h->n, m = h->m;
+  int r_ = h->bXin.ensure(8 * (size_t)B * n * m + 8 * (size_t)B + 64); if (r_) return r_;
+  double* dX = h->bXin.as<double>();
+  double* dout = dX + (size_t)B * n * m;
+  HIPCHK(hipMemcpyAsync(dX, X, 8 * (size_t)B * n * m, hipMemcpyHostToDevice, h->stream));
+  omc_launch_eval_objective(B, (int)n, (int)m, h->gamma, h->dA.as<double>(), h->dmask.as<uint8_t>(), dX, dout, h->stream);
+  HIPCHK(hipMemcpyAsync(objective, dout, 8 * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int omc_separation_batch(omc_instance* h, int B, int breakpoints, const double* Y, const double* U, double* eigvals,
+                         double* x, int* feasible) {
+  if (!h || !Y || !U) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (breakpoints != OMC_SMALLEST_1_EIGVEC && breakpoints != OMC_SMALLEST_2_EIGVEC)
+    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts breakpoints (OMC.jl:2440-2446)");
+  // stage an empty batch to get a workspace of the right size, then overwrite (Y, U)
+  std::vector<int> L(B, 0);
+  omc_relax_params P = h->params; P.breakpoints = breakpoints;
+  int rc = omc_relax_stage(h, B, &P, OMC_CUT_LINEAR, L.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  const OmcWS& w = h->ws;
+  const size_t n = h->n, k = h->k;
+  HIPCHK(hipMemcpyAsync(w.Y, Y, 8 * (size_t)B * n * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(w.U, U, 8 * (size_t)B * n * k, hipMemcpyHostToDevice, h->stream));
+  omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, h->stream);
+  std::vector<double> ev(2 * (size_t)B);
+  HIPCHK(hipMemcpyAsync(ev.data(), w.lmin, 16 * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+  if (x) HIPCHK(hipMemcpyAsync(x, w.bx, 8 * (size_t)B * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  for (int b = 0; b < B; ++b) {
+    if (eigvals) { eigvals[2 * b] = ev[2 * b]; eigvals[2 * b + 1] = ev[2 * b + 1]; }
+    if (feasible) feasible[b] = ev[2 * b] >= -1e-6 ? 1 : 0;   // OMC.jl:1274-1276 projection_tolerance
+  }
+  h->staged = false;
+  return 0;
+}
+
+int omc_round_Y_batch(omc_instance*, int, const double*, double*) {
+  return fail(OMC_ERR_UNSUPPORTED, "omc_round_Y_batch: not built yet");
+}
+
+int omc_altmin_batch(omc_instance*, int, int, int, const int*, const double*, const double*, const int8_t*,
+                     const double*, double, int, double, double*, double*, int*, int*, double*, double*) {
+  return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: not built yet");
+}
+
+int omc_last_solver_info(omc_instance* h, double* info) {
+  if (!h || !info) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  info[0] = h->last_solve_seconds; info[1] = (double)h->total_sweeps; info[2] = h->ws.rho; info[3] = (double)h->ws.rmax;
+  info[4] = (double)h->cone_use_lds; info[5] = (double)h->glob_use_lds; info[6] = (double)h->small_use_lds; info[7] = (double)h->ws.Rmax;
+  return 0;
+}
+
+int omc_last_kernel_stats(omc_instance* h, int64_t* launches, double* ms, int64_t* units) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  for (int c = 0; c < OMC_KERNEL_NCLASS; ++c) {
+    if (launches) launches[c] = h->launches[c];
+    if (ms) ms[c] = h->ms[c];
+    if (units) units[c] = h->units[c];
+  }
+  return 0;
+}
+
+}  // extern "C"

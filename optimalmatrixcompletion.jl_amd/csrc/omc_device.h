@@ -1,0 +1,90 @@
+// omc_device.h -- workspace descriptor shared by the kernels (omc_device.hip) and the host API (omc_api.cpp)
+#ifndef OMC_DEVICE_H
+#define OMC_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ROW_TRACE 0
+#define ROW_BOX 1
+#define ROW_BOUND 2
+#define ROW_CUT 3
+
+#define CONE_CLIP01 0
+#define CONE_EVALS 2
+#define CONE_SEP 3
+#define SMALL_PROJ 0
+#define SMALL_RECOVER 1
+
+#define OMC_ST_OPTIMAL 0
+#define OMC_ST_SLOW 1
+#define OMC_ST_TIME 2
+#define OMC_ST_INFEASIBLE 3
+
+#define NNQP_PMAX 48
+#define OMC_MAX_DYN_LDS (144 * 1024)
+
+struct OmcWS {
+  // sizes
+  int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks;
+  // parameters
+  double gamma, rho, rho_f, relax, eps_gap, eps_feas, sumA2;
+  // instance (device, read-only)
+  const int* col_ptr;     // m+1
+  const int* col_idx;     // nnz: observed rows of each column, ascending
+  const double* col_val;  // nnz: A at those
+  const double* Ncnt;     // n*n: number of columns observing both rows
+  const double* wY1;      // n*n: consensus weight of Y entries for rho = 1: rho_f_ratio*Ncnt + 2
+  // per-node state (node stride in comments)
+  double *Y, *Yp;         // n*n
+  double* U;              // n*k
+  double *D1, *D3;        // n*n scaled duals of the two full-Y cone blocks
+  double *W1, *E3;        // n*n: clip(Y-D1) ; Q dS Q'
+  double* Qb;             // n*rmax: orthonormal basis of the row functionals of node b; rr[b] columns used
+  int* rr;                // B
+  double *Vt, *D3V, *W3V, *Q3V;  // rmax*k
+  double *D3T, *W3T, *Q3T;       // k*k
+  double* dS;             // rmax*rmax
+  double *alpha, *alphaX; // nnz
+  double* sval;           // m
+  double* Mchk;           // n*n
+  // rows
+  int* R;                 // B
+  int *rkind, *rcut, *rbi, *rbj;  // B*Rmax
+  double* rcoef;          // B*Rmax*k
+  double* rrhs;           // B*Rmax
+  double* cutx;           // B*Lmax*n
+  double* G;              // B*Rmax*Rmax
+  double* lam;            // B*Rmax
+  // scalars per node
+  double *obj, *objout, *objprev, *lbprev, *lb, *c0, *evsum, *cpen, *cst, *rp, *rd, *lmin;  // B (lmin 2B)
+  double* bx;             // B*n
+  int *done, *status, *iters, *sweeps, *stall;
+  // scratch
+  double* cp_scratch;  size_t cp_scratch_stride;   // per wave (B*m waves) when a column is too large for LDS
+  int cp_lds_c; int cp_lds_doubles;
+  double* cone_scratch; size_t cone_scratch_stride; // per node when N is too large for LDS
+  double* glob_scratch; size_t glob_scratch_stride;
+  double* small_scratch; size_t small_scratch_stride;
+  double* chk_scratch;   // B*n*k
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+void omc_launch_setup(const OmcWS* w, hipStream_t s);
+void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s);
+void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s);
+void omc_launch_global(const OmcWS* w, int use_lds, size_t lds_bytes, hipStream_t s);
+void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s);
+void omc_launch_check_zero(const OmcWS* w, hipStream_t s);
+void omc_launch_check_build(const OmcWS* w, hipStream_t s);
+void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);
+void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s);
+void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s);
+void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,
+                               double* out, hipStream_t s);
+int omc_set_max_lds(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

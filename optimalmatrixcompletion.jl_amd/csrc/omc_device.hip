@@ -1,0 +1,1136 @@
+// omc_device.hip -- CDNA4 (gfx950) kernels of the node-relaxation engine.
+//
+// Hot path = per-B&B-node relaxation of OptimalMatrixCompletion.jl (OMC.jl:1431-1943) restated as
+//     min f(Y) = 1/2 sum_j a_j'(I + gamma Y[O_j,O_j])^-1 a_j   over  {[Y U;U' I]>=0, Y<=I, trY<=k, rows}
+// and solved by a consensus ADMM.  Only v = X'U enters the rows, so with Q an orthonormal
+// basis of the row functionals the order-(n+k) cone is replaced by 0 <= Y <= I plus the order-(r+k) cone
+// [Q'YQ Vt; Vt' I] >= 0, Vt = Q'U.  One ADMM iteration is four kernel classes, each batched over B nodes:
+//   k_colprox : one WAVE per (node, column)  -- secular-equation prox of one column block (Cholesky + Newton)
+//   k_cone    : one WORKGROUP per node       -- LDS-resident one-sided Jacobi eigensolver + spectral clip to [0,1]
+//   k_small   : one WORKGROUP per node       -- the small cone (order r+k), same Jacobi routine
+//   k_global  : one WORKGROUP per node       -- consensus average, exact projection on the linear rows (NNQP),
+//                                               dual updates, residuals
+// plus k_check* (certificate: exact f(Y), Lagrangian dual bound) every `check_every` iterations.
+// Wavefront = 64 everywhere.  No CUDA compatibility paths.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "omc_device.h"
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ double group_sum(double v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+// block-wide sum, result valid in every thread; red must hold >= 32 doubles
+__device__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_setup: initial iterate + Gram matrix (for rho = 1) of the linear rows in the metric of the consensus weights
+//   rows of node b:  <CY_r, Y> + <CU_r, U> <= rhs_r ;  CY_r = I (trace) | x x' (cut) | 0 ;  CU_r = x (x) coef_r
+//   (bound / cut rows) or a single entry (box rows).   G1_rr' = <CY_r, CY_r'>_{1/wY1} + <CU_r, CU_r'> / 2
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rowU_entry(const OmcWS& w, int b, int r, int i, int j) {
+  // coefficient of U[i][j] in row r of node b
+  const int kind = w.rkind[(size_t)b * w.Rmax + r];
+  if (kind == ROW_TRACE) return 0.0;
+  if (kind == ROW_BOX) {
+    return (w.rbi[(size_t)b * w.Rmax + r] == i && w.rbj[(size_t)b * w.Rmax + r] == j)
+               ? w.rcoef[((size_t)b * w.Rmax + r) * w.k]
+               : 0.0;
+  }
+  const int l = w.rcut[(size_t)b * w.Rmax + r];
+  return w.cutx[((size_t)b * w.Lmax + l) * w.n + i] * w.rcoef[((size_t)b * w.Rmax + r) * w.k + j];
+}
+
+__global__ void k_setup(OmcWS w) {
+  const int b = blockIdx.x, n = w.n, k = w.k, tid = threadIdx.x, T = blockDim.x, rm = w.rmax;
+  __shared__ double red[32];
+  double* Y = w.Y + (size_t)b * n * n;
+  double* Yp = w.Yp + (size_t)b * n * n;
+  const double d0 = (double)k / (double)n;
+  for (int e = tid; e < n * n; e += T) {
+    int i = e % n, j = e / n;
+    double v = (i == j) ? d0 : 0.0;
+    Y[e] = v; Yp[e] = v;
+    w.D1[(size_t)b * n * n + e] = 0.0; w.D3[(size_t)b * n * n + e] = 0.0; w.E3[(size_t)b * n * n + e] = 0.0;
+  }
+  for (int e = tid; e < n * k; e += T) w.U[(size_t)b * n * k + e] = 0.0;
+  for (int e = tid; e < rm * k; e += T) {
+    w.Vt[(size_t)b * rm * k + e] = 0.0; w.D3V[(size_t)b * rm * k + e] = 0.0;
+    w.W3V[(size_t)b * rm * k + e] = 0.0; w.Q3V[(size_t)b * rm * k + e] = 0.0;
+  }
+  for (int e = tid; e < k * k; e += T) {
+    w.D3T[(size_t)b * k * k + e] = 0.0; w.Q3T[(size_t)b * k * k + e] = 0.0;
+    w.W3T[(size_t)b * k * k + e] = ((e % k) == (e / k)) ? 1.0 : 0.0;
+  }
+  for (int e = tid; e < w.nnz; e += T) w.alpha[(size_t)b * w.nnz + e] = 0.0;
+  for (int e = tid; e < w.m; e += T) w.sval[(size_t)b * w.m + e] = -1.0;
+  const int R = w.R[b];
+  for (int e = tid; e < w.Rmax; e += T) w.lam[(size_t)b * w.Rmax + e] = 0.0;
+  if (tid == 0) {
+    w.done[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0;
+    w.obj[b] = 1e300; w.objout[b] = 1e300; w.objprev[b] = 1e300; w.lbprev[b] = -1e300; w.lb[b] = -1e300; w.rp[b] = 1e300; w.rd[b] = 1e300;
+  }
+  // Gram matrix for rho = 1
+  double* G = w.G + (size_t)b * w.Rmax * w.Rmax;
+  for (int r = 0; r < R; ++r) {
+    const int kr = w.rkind[(size_t)b * w.Rmax + r];
+    for (int s = r; s < R; ++s) {
+      const int ks = w.rkind[(size_t)b * w.Rmax + s];
+      double acc = 0.0;
+      const bool yr = (kr == ROW_TRACE || kr == ROW_CUT), ys = (ks == ROW_TRACE || ks == ROW_CUT);
+      if (yr && ys) {
+        const double* xr = (kr == ROW_CUT) ? w.cutx + ((size_t)b * w.Lmax + w.rcut[(size_t)b * w.Rmax + r]) * n : nullptr;
+        const double* xs = (ks == ROW_CUT) ? w.cutx + ((size_t)b * w.Lmax + w.rcut[(size_t)b * w.Rmax + s]) * n : nullptr;
+        if (!xr && !xs) {
+          for (int i = tid; i < n; i += T) acc += 1.0 / w.wY1[(size_t)i * n + i];
+        } else if (!xr || !xs) {
+          const double* x = xr ? xr : xs;
+          for (int i = tid; i < n; i += T) acc += x[i] * x[i] / w.wY1[(size_t)i * n + i];
+        } else {
+          for (int e = tid; e < n * n; e += T) {
+            int i = e % n, j = e / n;
+            acc += xr[i] * xr[j] * xs[i] * xs[j] / w.wY1[e];
+          }
+        }
+      }
+      if (kr != ROW_TRACE && ks != ROW_TRACE) {
+        for (int e = tid; e < n * k; e += T) {
+          int i = e % n, j = e / n;
+          double a = rowU_entry(w, b, r, i, j);
+          if (a != 0.0) acc += a * rowU_entry(w, b, s, i, j) * 0.5;
+        }
+      }
+      double tot = block_sum(acc, red);
+      if (tid == 0) { G[(size_t)r * w.Rmax + s] = tot; G[(size_t)s * w.Rmax + r] = tot; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_colprox: one wave per (node b, column j).
+//   mode 0 (prox):   B = I + gamma*((2Y - Yp)[O,O] - gamma/(2 rho_f) a_old a_old'),  cp = gamma^2/(2 rho_f)
+//                    find s >= 0:  || (B + cp s I)^-1 a ||^2 = s   (phi convex decreasing -> Newton from the left)
+//                    alpha = (B + cp s I)^-1 a
+//   mode 1 (exact):  B = I + gamma*Y[O,O], alpha = B^-1 a ;  obj += 1/2 a'alpha ; c0 += a'alpha - 1/2||alpha||^2
+// The c x c matrix lives in LDS (c <= CP_LDS_C) or in a per-wave global scratch slab.
+// ---------------------------------------------------------------------------------------------------------
+#define TRI(r, q) ((size_t)(r) * ((r) + 1) / 2 + (q))
+#define WAVE_SYNC()                                      \
+  do {                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                     \
+  } while (0)
+
+// in-place Cholesky of a symmetric matrix stored as packed lower triangle (row r holds q = 0..r)
+__device__ bool wave_cholesky(double* Lm, int c, int lane) {
+  for (int kk = 0; kk < c; ++kk) {
+    double piv = Lm[TRI(kk, kk)];
+    if (!(piv > 0.0)) return false;
+    double d = sqrt(piv);
+    WAVE_SYNC();
+    for (int r = kk + lane; r < c; r += WAVE) {
+      double v = (r == kk) ? d : Lm[TRI(r, kk)] / d;
+      Lm[TRI(r, kk)] = v;
+    }
+    WAVE_SYNC();
+    const int t = c - kk - 1;
+    const int tot = t * t;
+    for (int e = lane; e < tot; e += WAVE) {
+      int rr = e / t, qq = e - rr * t;
+      if (qq <= rr) {
+        int r = kk + 1 + rr, q = kk + 1 + qq;
+        Lm[TRI(r, q)] -= Lm[TRI(r, kk)] * Lm[TRI(q, kk)];
+      }
+    }
+    WAVE_SYNC();
+  }
+  return true;
+}
+
+// solve L L' y = rhs (packed L); y, rhs length c
+__device__ void wave_chol_solve(const double* Lm, int c, const double* rhs, double* y, int lane) {
+  for (int r = 0; r < c; ++r) {
+    double p = 0.0;
+    for (int q = lane; q < r; q += WAVE) p += Lm[TRI(r, q)] * y[q];
+    p = wave_sum(p);
+    if (lane == 0) y[r] = (rhs[r] - p) / Lm[TRI(r, r)];
+    WAVE_SYNC();
+  }
+  for (int r = c - 1; r >= 0; --r) {
+    double p = 0.0;
+    for (int q = r + 1 + lane; q < c; q += WAVE) p += Lm[TRI(q, r)] * y[q];
+    p = wave_sum(p);
+    if (lane == 0) y[r] = (y[r] - p) / Lm[TRI(r, r)];
+    WAVE_SYNC();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
+  extern __shared__ double smem[];
+  const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int gw = blockIdx.x * wpb + wave_in_blk;  // global wave id
+  const int b = gw / w.m, j = gw - b * w.m;
+  if (b >= w.B) return;
+  if (w.done[b]) return;
+  const int n = w.n;
+  const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
+  if (c == 0) return;
+  const size_t tri = (size_t)c * (c + 1) / 2;
+  // per-wave storage: Bm, Lm (packed lower triangles), vectors a, y, z, alpha_old
+  double* base;
+  if (c <= w.cp_lds_c) base = smem + (size_t)wave_in_blk * w.cp_lds_doubles;
+  else base = w.cp_scratch + (size_t)gw * w.cp_scratch_stride;
+  double* Bm = base;
+  double* Lm = Bm + tri;
+  double* va = Lm + tri;
+  double* vy = va + c;
+  double* vz = vy + c;
+  double* vo = vz + c;
+  const int* idx = w.col_idx + off;
+  const double g = w.gamma;
+  const double* Y = w.Y + (size_t)b * n * n;
+  const double* Yp = w.Yp + (size_t)b * n * n;
+  double* alpha = ((mode == 0) ? w.alpha : w.alphaX) + (size_t)b * w.nnz + off;
+  for (int p = lane; p < c; p += WAVE) {
+    va[p] = w.col_val[off + p];
+    vo[p] = (mode == 0) ? alpha[p] : 0.0;
+  }
+  WAVE_SYNC();
+  const double coef = (mode == 0) ? g / (2.0 * w.rho_f) : 0.0;
+  for (int e = lane; e < c * c; e += WAVE) {
+    int p = e / c, q = e - p * c;
+    if (q > p) continue;
+    size_t a = (size_t)idx[q] * n + idx[p];
+    double yv = (mode == 0) ? (2.0 * Y[a] - Yp[a]) : Y[a];
+    double v = g * (yv - coef * vo[p] * vo[q]);
+    if (p == q) v += 1.0;
+    Bm[TRI(p, q)] = v;
+  }
+  WAVE_SYNC();
+  double s = 0.0;
+  if (mode == 0) {
+    const double cp = g * g / (2.0 * w.rho_f);
+    double sprev = w.sval[(size_t)b * w.m + j];
+    s = (sprev > 0.0) ? sprev : 0.0;
+    double lo = 0.0, hi = -1.0;  // hi < 0: unknown
+    bool lo_valid = false;       // lo_valid: Cholesky succeeded at lo and phi(lo) >= 0
+    for (int it = 0; it < 60; ++it) {
+      for (int e = lane; e < c * c; e += WAVE) {
+        int p = e / c, q = e - p * c;
+        if (q <= p) Lm[TRI(p, q)] = Bm[TRI(p, q)] + ((p == q) ? cp * s : 0.0);
+      }
+      WAVE_SYNC();
+      bool ok = wave_cholesky(Lm, c, lane);
+      if (!ok) {  // s below the PD range: move right
+        lo = s; lo_valid = false;
+        s = (hi > 0.0) ? 0.5 * (s + hi) : (2.0 * s + 1.0);
+        continue;
+      }
+      wave_chol_solve(Lm, c, va, vy, lane);
+      wave_chol_solve(Lm, c, vy, vz, lane);
+      double yy = 0.0, yz = 0.0;
+      for (int p = lane; p < c; p += WAVE) { yy += vy[p] * vy[p]; yz += vy[p] * vz[p]; }
+      yy = wave_sum(yy); yz = wave_sum(yz);
+      const double ph = yy - s, dph = -2.0 * cp * yz - 1.0;
+      if (ph >= 0.0) { lo = s; lo_valid = true; } else { hi = s; }
+      double sn = s - ph / dph;
+      if (!(sn > lo) && !lo_valid) sn = 0.5 * (lo + s);
+      if (sn < lo) sn = lo;
+      if (hi > 0.0 && sn > hi) sn = 0.5 * (lo + hi);
+      if (fabs(sn - s) <= 4e-16 * fmax(1.0, fabs(s))) { s = sn; break; }
+      s = sn;
+    }
+    // final solve at the converged s (vy currently holds the solve at the previous s: redo once, cheap)
+    for (int e = lane; e < c * c; e += WAVE) {
+      int p = e / c, q = e - p * c;
+      if (q <= p) Lm[TRI(p, q)] = Bm[TRI(p, q)] + ((p == q) ? cp * s : 0.0);
+    }
+    WAVE_SYNC();
+    wave_cholesky(Lm, c, lane);
+    wave_chol_solve(Lm, c, va, vy, lane);
+    if (lane == 0) w.sval[(size_t)b * w.m + j] = s;
+    for (int p = lane; p < c; p += WAVE) alpha[p] = vy[p];
+  } else {
+    for (int e = lane; e < c * c; e += WAVE) {
+      int p = e / c, q = e - p * c;
+      if (q <= p) Lm[TRI(p, q)] = Bm[TRI(p, q)];
+    }
+    WAVE_SYNC();
+    bool ok = wave_cholesky(Lm, c, lane);
+    if (!ok) {  // Y not PSD enough on this block: report +inf objective contribution
+      if (lane == 0) atomicAdd(&w.obj[b], 1e300);
+      return;
+    }
+    wave_chol_solve(Lm, c, va, vy, lane);
+    double aa = 0.0, al2 = 0.0;
+    for (int p = lane; p < c; p += WAVE) { aa += va[p] * vy[p]; al2 += vy[p] * vy[p]; alpha[p] = vy[p]; }
+    aa = wave_sum(aa); al2 = wave_sum(al2);
+    if (lane == 0) {
+      atomicAdd(&w.obj[b], 0.5 * aa);
+      atomicAdd(&w.c0[b], aa - 0.5 * al2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_cone: symmetric eigendecomposition by one-sided (Hestenes) Jacobi on the SHIFTED matrix M' = M + sigma I,
+// sigma = 1.5 ||M||_F, so that M' is positive definite with condition <= 5.  Columns g_t of G = M' V are then
+// orthogonal with ||g_t|| = lambda_t + sigma and v_t = g_t / ||g_t||: no eigenvector accumulation, one N x N
+// array, LDS-resident for N <= ~136.  Parallel (round-robin) ordering: Np/2 disjoint column pairs per step, each
+// handled by `lpp` lanes that split the rows, reduce the three inner products with wave shuffles and apply the
+// rotation from registers.
+//   mode CONE_CLIP01: M = Y - D1 (n x n)         -> W1 = V clip(lambda,0,1) V'   (the cone block 0 <= Y <= I)
+//   mode CONE_EVALS : M = Mchk (n x n)           -> sum of min(lam_i,0) over the k smallest -> evsum[b]
+//   mode CONE_SEP   : M = U U' - Y               -> two smallest eigenpairs -> lmin[2b..], bx
+// ---------------------------------------------------------------------------------------------------------
+#define JROWS 20  // rows cached in registers per lane
+
+__device__ __forceinline__ void rr_pair(int step, int t, int Np, int& p, int& q) {
+  // round-robin tournament on Np (even) players: step in [0,Np-1), t in [0,Np/2)
+  const int M1 = Np - 1;
+  if (t == 0) { p = step; q = Np - 1; }
+  else { p = (step + t) % M1; q = (step - t + M1) % M1; }
+  if (p > q) { int tmp = p; p = q; q = tmp; }
+}
+
+__device__ int jacobi_onesided(double* Gm, int Nr, int Np, int ld, int lpp, double tau, int max_sweeps, int* s_cnt) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int ngroups = T / lpp, grp = tid / lpp, lg = tid % lpp;
+  const int npairs = Np >> 1;
+  const bool cached = (Nr + lpp - 1) / lpp <= JROWS;
+  int sweeps = 0;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    for (int step = 0; step < Np - 1; ++step) {
+      for (int pr = grp; pr < npairs; pr += ngroups) {
+        int p, q;
+        rr_pair(step, pr, Np, p, q);
+        double* gp = Gm + (size_t)p * ld;
+        double* gq = Gm + (size_t)q * ld;
+        double a = 0.0, bb = 0.0, gm = 0.0;
+        double cp_[JROWS], cq_[JROWS];
+        if (cached) {
+#pragma unroll
+          for (int i = 0; i < JROWS; ++i) {
+            int r = lg + i * lpp;
+            double x = 0.0, y = 0.0;
+            if (r < Nr) { x = gp[r]; y = gq[r]; }
+            cp_[i] = x; cq_[i] = y;
+            a += x * x; bb += y * y; gm += x * y;
+          }
+        } else {
+          for (int r = lg; r < Nr; r += lpp) { double x = gp[r], y = gq[r]; a += x * x; bb += y * y; gm += x * y; }
+        }
+        a = group_sum(a, lpp); bb = group_sum(bb, lpp); gm = group_sum(gm, lpp);
+        if (fabs(gm) > tau * sqrt(a * bb) && a > 0.0 && bb > 0.0) {
+          const double zeta = (bb - a) / (2.0 * gm);
+          const double tt = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+          if (cached) {
+#pragma unroll
+            for (int i = 0; i < JROWS; ++i) {
+              int r = lg + i * lpp;
+              if (r < Nr) { gp[r] = cs * cp_[i] - sn * cq_[i]; gq[r] = sn * cp_[i] + cs * cq_[i]; }
+            }
+          } else {
+            for (int r = lg; r < Nr; r += lpp) { double x = gp[r], y = gq[r]; gp[r] = cs * x - sn * y; gq[r] = sn * x + cs * y; }
+          }
+          if (lg == 0) atomicAdd(s_cnt, 1);
+        }
+      }
+      __syncthreads();
+    }
+    int cnt = *s_cnt;
+    __syncthreads();
+    if (cnt == 0) { ++sweeps; break; }
+  }
+  return sweeps;
+}
+
+__device__ __forceinline__ double cone_M_entry(const OmcWS& w, int b, int mode, int i, int j) {
+  const int n = w.n, k = w.k;
+  if (mode == CONE_CLIP01) {
+    return w.Y[(size_t)b * n * n + (size_t)j * n + i] - w.D1[(size_t)b * n * n + (size_t)j * n + i];
+  } else if (mode == CONE_EVALS) {
+    return w.Mchk[(size_t)b * n * n + (size_t)j * n + i];
+  } else {  // CONE_SEP: U U' - Y
+    double s = 0.0;
+    for (int t = 0; t < k; ++t) s += w.U[(size_t)b * n * k + (size_t)t * n + i] * w.U[(size_t)b * n * k + (size_t)t * n + j];
+    return s - w.Y[(size_t)b * n * n + (size_t)j * n + i];
+  }
+}
+
+// Rebuild  out = base*M + sum_{s<nsel} wgt[s] * g_sel[s] g_sel[s]'   in 4x4 register tiles over the lower triangle.
+// `entry(i,j)` returns the original M (only evaluated when base != 0).
+template <class EntryF, class StoreF>
+__device__ void spectral_rebuild(const double* Gm, int ld, int N, const int* sel, const double* wgt, int nsel, double base,
+                                 EntryF entry, StoreF store) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int nt = (N + 3) >> 2;
+  const int ntiles = nt * (nt + 1) / 2;
+  for (int tile = tid; tile < ntiles; tile += T) {
+    int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int i0 = ti * 4, j0 = tj * 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
+    for (int s = 0; s < nsel; ++s) {
+      const double* gt = Gm + (size_t)sel[s] * ld;
+      const double ws = wgt[s];
+      double gi[4], gj[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { gi[a] = (i0 + a < N) ? gt[i0 + a] : 0.0; gj[a] = (j0 + a < N) ? gt[j0 + a] * ws : 0.0; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] += gi[a] * gj[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = i0 + a, j = j0 + c;
+        if (i < N && j < N && i >= j) {
+          double Mv = entry(i, j);
+          store(i, j, base * Mv + acc[a][c], Mv);
+        }
+      }
+  }
+}
+
+// common front end: load the symmetrised matrix into Gm (Np x ld), shift, Jacobi, squared column norms -> ev
+template <class EntryF>
+__device__ double eig_frontend(double* Gm, double* ev, int N, int Np, int ld, EntryF entry, double* red, int* s_cnt, int* sweeps_out) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  double fro = 0.0;
+  for (int e = tid; e < Np * Np; e += T) {
+    int i = e % Np, j = e / Np;
+    double v = 0.0;
+    if (i < N && j < N) { v = 0.5 * (entry(i, j) + entry(j, i)); fro += v * v; }
+    Gm[(size_t)j * ld + i] = v;
+  }
+  fro = sqrt(block_sum(fro, red));
+  const double sigma = 1.5 * fro + 1e-300;
+  for (int i = tid; i < N; i += T) Gm[(size_t)i * ld + i] += sigma;
+  __syncthreads();
+  int lpp = 64;
+  while (lpp > 1 && lpp * (Np >> 1) > T) lpp >>= 1;
+  const double tau = fmax(1e-14, 2.2e-16 * N);
+  int sweeps = jacobi_onesided(Gm, N, Np, ld, lpp, tau, 30, s_cnt);
+  if (sweeps_out && tid == 0) *sweeps_out += sweeps;
+  const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
+  for (int t = wv; t < N; t += nw) {
+    double a = 0.0;
+    for (int r = lane; r < N; r += WAVE) { double x = Gm[(size_t)t * ld + r]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) ev[t] = a;
+  }
+  __syncthreads();
+  return sigma;
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
+  extern __shared__ double smem[];
+  __shared__ double red[32];
+  __shared__ int s_cnt;
+  __shared__ int s_nsel;
+  __shared__ double s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b] && mode != CONE_SEP) return;
+  const int n = w.n, k = w.k;
+  const int N = n;
+  const int Np = (N + 1) & ~1, ld = Np | 1;
+  // with USE_LDS the pointers stay in the LDS address space (ds_read/ds_write, not flat)
+  auto Gm = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.cone_scratch + (size_t)b * w.cone_scratch_stride; }();
+  auto ev = Gm + (size_t)Np * ld;
+  auto wgt = ev + Np;
+  int* sel = (int*)(wgt + Np);
+  auto entry = [&](int i, int j) { return cone_M_entry(w, b, mode, i, j); };
+  const double sigma = eig_frontend(Gm, ev, N, Np, ld, entry, red, &s_cnt, w.sweeps + b);
+  if (mode == CONE_EVALS) {
+    if (tid == 0) {
+      double best[8]; int kk = (k < 8) ? k : 8;
+      for (int i = 0; i < kk; ++i) best[i] = 1e300;
+      for (int t = 0; t < N; ++t) {
+        double lamv = sqrt(ev[t]) - sigma;
+        for (int i = 0; i < kk; ++i) if (lamv < best[i]) { double tmp = best[i]; best[i] = lamv; lamv = tmp; }
+      }
+      double s = 0.0;
+      for (int i = 0; i < kk; ++i) s += fmin(best[i], 0.0);
+      w.evsum[b] = s;
+    }
+    return;
+  }
+  if (mode == CONE_SEP) {
+    __shared__ int s_i1, s_i2;
+    __shared__ double s_sg1, s_sg2, s_w1, s_w2;
+    if (tid == 0) {
+      int i1 = 0, i2 = -1; double l1 = 1e300, l2 = 1e300;
+      for (int t = 0; t < N; ++t) {
+        double lamv = sqrt(ev[t]) - sigma;
+        if (lamv < l1) { l2 = l1; i2 = i1; l1 = lamv; i1 = t; }
+        else if (lamv < l2) { l2 = lamv; i2 = t; }
+      }
+      if (i2 < 0) { i2 = i1; l2 = l1; }
+      s_i1 = i1; s_i2 = i2;
+      w.lmin[2 * b] = l1; w.lmin[2 * b + 1] = l2;
+      const double* g1 = Gm + (size_t)i1 * ld; const double* g2 = Gm + (size_t)i2 * ld;
+      int a1 = 0, a2 = 0;
+      for (int r = 1; r < N; ++r) { if (fabs(g1[r]) > fabs(g1[a1])) a1 = r; if (fabs(g2[r]) > fabs(g2[a2])) a2 = r; }
+      s_sg1 = ((g1[a1] >= 0.0) ? 1.0 : -1.0) / sqrt(ev[i1]);
+      s_sg2 = ((g2[a2] >= 0.0) ? 1.0 : -1.0) / sqrt(ev[i2]);
+      if (w.breakpoints == 2 && l2 < -1e-10) {       // OMC.jl:2471-2473
+        double nn = sqrt(l1 * l1 + l2 * l2);
+        s_w1 = fabs(l1) / nn; s_w2 = fabs(l2) / nn;
+      } else { s_w1 = 1.0; s_w2 = 0.0; }
+    }
+    __syncthreads();
+    for (int r = tid; r < N; r += T)
+      w.bx[(size_t)b * n + r] = s_w1 * s_sg1 * Gm[(size_t)s_i1 * ld + r] + s_w2 * s_sg2 * Gm[(size_t)s_i2 * ld + r];
+    return;
+  }
+  // CONE_CLIP01: W1 = V clip(lambda, 0, 1) V'.  Either rebuild the defect (lambda<0 or >1) on top of M, or the kept part.
+  if (tid == 0) {
+    int ndef = 0, nkeep = 0;
+    for (int t = 0; t < N; ++t) {
+      double lamv = sqrt(ev[t]) - sigma;
+      if (lamv < 0.0 || lamv > 1.0) ++ndef;
+      if (lamv > 0.0) ++nkeep;
+    }
+    int c = 0;
+    if (ndef <= nkeep) {
+      for (int t = 0; t < N; ++t) {
+        double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
+        if (lamv < 0.0) { sel[c] = t; wgt[c] = -lamv / nu2; ++c; }
+        else if (lamv > 1.0) { sel[c] = t; wgt[c] = -(lamv - 1.0) / nu2; ++c; }
+      }
+      s_base = 1.0;
+    } else {
+      for (int t = 0; t < N; ++t) {
+        double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
+        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, 1.0) / nu2; ++c; }
+      }
+      s_base = 0.0;
+    }
+    s_nsel = c;
+  }
+  __syncthreads();
+  double* Wout = w.W1 + (size_t)b * n * n;
+  auto entry2 = [&](int i, int j) { return 0.5 * (cone_M_entry(w, b, mode, i, j) + cone_M_entry(w, b, mode, j, i)); };
+  auto store = [&](int i, int j, double v, double) { Wout[(size_t)j * n + i] = v; Wout[(size_t)i * n + j] = v; };
+  spectral_rebuild(Gm, ld, N, sel, wgt, s_nsel, s_base, entry2, store);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_small: the small cone  [S Vt; Vt' T] >= 0,  S = Q'(Y - D3)Q (r x r),  Vt - D3V (r x k),  T = I - D3T.
+//   mode SMALL_PROJ   : P3 = P_+(M3);  Q3 = P3 - M3 (>= 0: the multiplier direction);
+//                       dS = Q3_11, E3 = Q dS Q' (n x n), W3V = P3_12, W3T = P3_22, Q3V = Q3_12, Q3T = Q3_22
+//   mode SMALL_RECOVER: U = Y Q (Q'YQ)^+ Vt  (a U with U U' <= Y and Q'U = Vt)
+// One workgroup per node; T1 = (Y - D3) Q is staged in dynamic LDS or global scratch.
+// ---------------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
+  extern __shared__ double smem[];
+  __shared__ double red[32];
+  __shared__ int s_cnt, s_nsel;
+  __shared__ double s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b] && mode == SMALL_PROJ) return;
+  const int n = w.n, k = w.k, rm = w.rmax;
+  const int r = w.rr[b];
+  const int N3 = (mode == SMALL_PROJ) ? r + k : r;
+  const int Np = (N3 + 1) & ~1, ld = Np | 1;
+  auto base = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.small_scratch + (size_t)b * w.small_scratch_stride; }();
+  double* T1 = base;                         // n x r
+  double* M3 = T1 + (size_t)n * rm;          // N3max x N3max  (column-major, ld3 = rm + k)
+  const int ld3 = rm + k;
+  double* Gm = M3 + (size_t)ld3 * ld3;       // Jacobi work
+  const int Npm = (rm + k + 1) & ~1, ldm = Npm | 1;
+  double* ev = Gm + (size_t)Npm * ldm;
+  double* wgt = ev + Npm;
+  int* sel = (int*)(wgt + Npm);
+  double* Cc = (double*)(sel + Npm + (Npm & 1));  // r x k coefficients (recover)
+  const double* Q = w.Qb + (size_t)b * n * rm;
+  const double* Y = w.Y + (size_t)b * n * n;
+  const double* D3 = w.D3 + (size_t)b * n * n;
+  const double* Vt = w.Vt + (size_t)b * rm * k;
+  // T1 = (Y - D3) Q   or  Y Q
+  for (int e = tid; e < n * r; e += T) {
+    int i = e % n, a = e / n;
+    double acc = 0.0;
+    if (mode == SMALL_PROJ) for (int j = 0; j < n; ++j) acc += (Y[(size_t)j * n + i] - D3[(size_t)j * n + i]) * Q[(size_t)a * n + j];
+    else for (int j = 0; j < n; ++j) acc += Y[(size_t)j * n + i] * Q[(size_t)a * n + j];
+    T1[(size_t)a * n + i] = acc;
+  }
+  __syncthreads();
+  // M3
+  for (int e = tid; e < N3 * N3; e += T) {
+    int i = e % N3, j = e / N3;
+    double v;
+    if (i < r && j < r) { v = 0.0; for (int t = 0; t < n; ++t) v += Q[(size_t)i * n + t] * T1[(size_t)j * n + t]; }
+    else if (i < r) v = Vt[(size_t)(j - r) * rm + i] - w.D3V[(size_t)b * rm * k + (size_t)(j - r) * rm + i];
+    else if (j < r) v = Vt[(size_t)(i - r) * rm + j] - w.D3V[(size_t)b * rm * k + (size_t)(i - r) * rm + j];
+    else v = ((i == j) ? 1.0 : 0.0) - w.D3T[(size_t)b * k * k + (size_t)(j - r) * k + (i - r)];
+    M3[(size_t)j * ld3 + i] = v;
+  }
+  __syncthreads();
+  if (N3 == 0) return;
+  auto entry = [&](int i, int j) { return M3[(size_t)j * ld3 + i]; };
+  const double sigma = eig_frontend(Gm, ev, N3, Np, ld, entry, red, &s_cnt, nullptr);
+  if (mode == SMALL_RECOVER) {
+    // pinv weights: S^+ = sum_{lam > tol} (1/lam) v v' ;  v = g/nu  ->  weight 1/(lam nu^2)
+    if (tid == 0) {
+      double lmax = 0.0;
+      for (int t = 0; t < N3; ++t) lmax = fmax(lmax, sqrt(ev[t]) - sigma);
+      const double tol = 1e-12 * fmax(1.0, lmax);
+      int c = 0;
+      for (int t = 0; t < N3; ++t) {
+        double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
+        if (lamv > tol) { sel[c] = t; wgt[c] = 1.0 / (lamv * nu2); ++c; }
+      }
+      s_nsel = c;
+    }
+    __syncthreads();
+    // Cc = S^+ Vt  (r x k)
+    for (int e = tid; e < r * k; e += T) {
+      int a = e % r, j = e / r;
+      double acc = 0.0;
+      for (int s = 0; s < s_nsel; ++s) {
+        const double* gt = Gm + (size_t)sel[s] * ld;
+        double dot = 0.0;
+        for (int c2 = 0; c2 < r; ++c2) dot += gt[c2] * Vt[(size_t)j * rm + c2];
+        acc += wgt[s] * gt[a] * dot;
+      }
+      Cc[(size_t)j * rm + a] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * k; e += T) {
+      int i = e % n, j = e / n;
+      double acc = 0.0;
+      for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Cc[(size_t)j * rm + a];
+      w.U[(size_t)b * n * k + e] = acc;
+    }
+    return;
+  }
+  // SMALL_PROJ: Q3 = P3 - M3 = sum_{lam<0} |lam| v v'   (or P3 directly when fewer positive eigenvalues)
+  if (tid == 0) {
+    int npos = 0, nneg = 0;
+    for (int t = 0; t < N3; ++t) { double lamv = sqrt(ev[t]) - sigma; if (lamv > 0.0) ++npos; else if (lamv < 0.0) ++nneg; }
+    const bool use_neg = nneg <= npos;
+    int c = 0;
+    for (int t = 0; t < N3; ++t) {
+      double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
+      if (use_neg ? (lamv < 0.0) : (lamv > 0.0)) { sel[c] = t; wgt[c] = fabs(lamv) / nu2; ++c; }
+    }
+    s_nsel = c; s_base = use_neg ? 1.0 : 0.0;   // base=1: acc is Q3; base=0: acc is P3
+  }
+  __syncthreads();
+  const bool acc_is_Q3 = (s_base == 1.0);
+  double* dS = w.dS + (size_t)b * rm * rm;
+  auto store = [&](int i, int j, double v, double Mv) {
+    // v = base*Mv + acc ; recover (P3, Q3) from acc
+    double accv = v - s_base * Mv;
+    double q3 = acc_is_Q3 ? accv : (accv - Mv);
+    double p3 = acc_is_Q3 ? (Mv + accv) : accv;
+    if (i < r && j < r) { dS[(size_t)j * rm + i] = q3; dS[(size_t)i * rm + j] = q3; }
+    else if (i >= r && j < r) {  // (row i in T block, col j in S block): V' entry -> store as V[j][i-r]
+      w.W3V[(size_t)b * rm * k + (size_t)(i - r) * rm + j] = p3;
+      w.Q3V[(size_t)b * rm * k + (size_t)(i - r) * rm + j] = q3;
+    } else if (i >= r && j >= r) {
+      w.W3T[(size_t)b * k * k + (size_t)(j - r) * k + (i - r)] = p3; w.W3T[(size_t)b * k * k + (size_t)(i - r) * k + (j - r)] = p3;
+      w.Q3T[(size_t)b * k * k + (size_t)(j - r) * k + (i - r)] = q3; w.Q3T[(size_t)b * k * k + (size_t)(i - r) * k + (j - r)] = q3;
+    }
+  };
+  spectral_rebuild(Gm, ld, N3, sel, wgt, s_nsel, s_base, entry, store);
+  __syncthreads();
+  __threadfence_block();
+  // E3 = Q dS Q'  (n x n): T1 <- Q dS (n x r), then E3 = T1 Q'
+  for (int e = tid; e < n * r; e += T) {
+    int i = e % n, a = e / n;
+    double acc = 0.0;
+    for (int c2 = 0; c2 < r; ++c2) acc += Q[(size_t)c2 * n + i] * dS[(size_t)a * rm + c2];
+    T1[(size_t)a * n + i] = acc;
+  }
+  __syncthreads();
+  double* E3 = w.E3 + (size_t)b * n * n;
+  for (int e = tid; e < n * n; e += T) {
+    int i = e % n, j = e / n;
+    if (i < j) continue;
+    double acc = 0.0;
+    for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Q[(size_t)a * n + j];
+    E3[(size_t)j * n + i] = acc; E3[(size_t)i * n + j] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// NNQP on one wave:  min 1/2 l'Gl - c'l, l >= 0  (Lawson-Hanson active set in QP form, warm-started from the
+// previous multipliers).  G is R x R (ld = Rmax) in global memory; the passive-set system (<= NNQP_PMAX) is
+// solved by Cholesky in LDS with a tiny ridge (parallel rows make G singular).
+// ---------------------------------------------------------------------------------------------------------
+__device__ void wave_nnqp(const double* G, int ldG, const double* cvec, double* lam, int R, double* Gp, double* sv,
+                          double* tmp, int* plist, int lane) {
+  // plist: passive indices (LDS, NNQP_PMAX ints); Gp: PMAX x (PMAX+1); sv,tmp: PMAX doubles
+  int np = 0;
+  // warm start: passive = {lam > 0}
+  for (int r = 0; r < R; ++r) {  // uniform over the wave (lam in LDS/global, same for all lanes)
+    if (lam[r] > 0.0 && np < NNQP_PMAX) { if (lane == 0) plist[np] = r; ++np; }
+    else if (lam[r] != 0.0) { if (lane == 0) lam[r] = 0.0; }
+  }
+  WAVE_SYNC();
+  double cmax = 0.0;
+  for (int r = lane; r < R; r += WAVE) cmax = fmax(cmax, fabs(cvec[r]));
+  for (int o = 32; o > 0; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o, WAVE));
+  const double tol = 1e-13 * fmax(cmax, 1e-300);
+  bool need_inner = (np > 0);
+  for (int outer = 0; outer < 3 * R + 10; ++outer) {
+    if (!need_inner) {
+      // w = c - G lam over non-passive rows; pick the max
+      double best = -1e300; int bi = -1;
+      for (int r = lane; r < R; r += WAVE) {
+        bool inP = false;
+        for (int a = 0; a < np; ++a) if (plist[a] == r) inP = true;
+        if (inP) continue;
+        double wv = cvec[r];
+        for (int a = 0; a < np; ++a) wv -= G[(size_t)r * ldG + plist[a]] * lam[plist[a]];
+        if (wv > best) { best = wv; bi = r; }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        double ob = __shfl_xor(best, o, WAVE); int oi = __shfl_xor(bi, o, WAVE);
+        if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
+      }
+      if (bi < 0 || best <= tol || np >= NNQP_PMAX) break;
+      if (lane == 0) plist[np] = bi;
+      ++np;
+      WAVE_SYNC();
+    }
+    need_inner = false;
+    // inner loop
+    for (int inner = 0; inner < 3 * NNQP_PMAX + 10; ++inner) {
+      double dmax = 0.0;
+      for (int e = lane; e < np * np; e += WAVE) {
+        int a = e / np, c2 = e - a * np;
+        if (c2 <= a) Gp[TRI(a, c2)] = G[(size_t)plist[a] * ldG + plist[c2]];
+      }
+      for (int a = 0; a < np; ++a) dmax = fmax(dmax, G[(size_t)plist[a] * ldG + plist[a]]);
+      WAVE_SYNC();
+      for (int a = lane; a < np; a += WAVE) { Gp[TRI(a, a)] += 1e-14 * dmax; tmp[a] = cvec[plist[a]]; }
+      WAVE_SYNC();
+      bool ok = wave_cholesky(Gp, np, lane);
+      if (!ok) {  // numerically singular: drop the newest index
+        --np; WAVE_SYNC();
+        if (np == 0) break;
+        continue;
+      }
+      wave_chol_solve(Gp, np, tmp, sv, lane);
+      // all positive?
+      double mins = 1e300;
+      for (int a = lane; a < np; a += WAVE) mins = fmin(mins, sv[a]);
+      for (int o = 32; o > 0; o >>= 1) mins = fmin(mins, __shfl_xor(mins, o, WAVE));
+      if (mins > 0.0) {
+        for (int a = lane; a < np; a += WAVE) lam[plist[a]] = sv[a];
+        WAVE_SYNC();
+        break;
+      }
+      // step toward s until the first multiplier hits zero
+      double al = 1e300;
+      for (int a = lane; a < np; a += WAVE) {
+        double lv = lam[plist[a]];
+        if (sv[a] <= 0.0) al = fmin(al, lv / (lv - sv[a]));
+      }
+      for (int o = 32; o > 0; o >>= 1) al = fmin(al, __shfl_xor(al, o, WAVE));
+      if (!(al >= 0.0)) al = 0.0;
+      for (int a = lane; a < np; a += WAVE) {
+        double lv = lam[plist[a]];
+        lam[plist[a]] = lv + al * (sv[a] - lv);
+      }
+      WAVE_SYNC();
+      // remove zeros (serial compaction, uniform)
+      int nn = 0; bool removed = false; double minl = 1e300; int mini = -1;
+      for (int a = 0; a < np; ++a) {
+        double lv = lam[plist[a]];
+        if (sv[a] <= 0.0 && lv < minl) { minl = lv; mini = a; }
+      }
+      for (int a = 0; a < np; ++a) {
+        int r = plist[a];
+        double lv = lam[r];
+        bool drop = (sv[a] <= 0.0) && (lv <= 1e-18 * fmax(cmax, 1e-300) || a == mini);
+        WAVE_SYNC();
+        if (drop) { if (lane == 0) lam[r] = 0.0; removed = true; }
+        else { if (lane == 0) { plist[nn] = r; } ++nn; }
+        WAVE_SYNC();
+      }
+      // sv must be compacted consistently: recomputed next inner iteration, so nothing to do
+      np = nn;
+      (void)removed;
+      if (np == 0) break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_global: consensus average + projection on the rows + dual updates (one workgroup per node)
+//   tY = [rho_f N.Y + gamma/2 LL + rho (rx W1 + (1-rx) Y + D1) + rho (Y + (1-rx) D3 + rx E3)] / (rho wY1)
+//   tV = rx W3V + (1-rx) Vt + D3V ;  tU = Q tV
+//   mu = argmin 1/2 mu'G1 mu - c'mu, mu >= 0 (c = A t - b) ;  lam = rho mu
+//   Yn = tY - A_Y' mu / wY1 ;  Vn = tV - Q'(A_U' mu)/2
+// ---------------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ void __launch_bounds__(512) k_global(OmcWS w) {
+  extern __shared__ double smem[];
+  __shared__ double red[32];
+  __shared__ double s_Gp[NNQP_PMAX * (NNQP_PMAX + 1) / 2];
+  __shared__ double s_sv[NNQP_PMAX], s_tmp[NNQP_PMAX];
+  __shared__ int s_pl[NNQP_PMAX];
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b]) return;
+  const int n = w.n, k = w.k, m = w.m, rm = w.rmax;
+  const int R = w.R[b], r = w.rr[b];
+  auto tY = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.glob_scratch + (size_t)b * w.glob_scratch_stride; }();
+  double* tU = tY + (size_t)n * n;       // n*k   (tU, then the full-space U correction)
+  double* tV = tU + (size_t)n * k;       // rm*k
+  double* cvec = tV + (size_t)rm * k;    // Rmax
+  double* mu = cvec + w.Rmax;            // Rmax
+  double* lam = w.lam + (size_t)b * w.Rmax;
+  double* Y = w.Y + (size_t)b * n * n;
+  double* Yp = w.Yp + (size_t)b * n * n;
+  double* U = w.U + (size_t)b * n * k;
+  double* D1 = w.D1 + (size_t)b * n * n;
+  double* D3 = w.D3 + (size_t)b * n * n;
+  double* Vt = w.Vt + (size_t)b * rm * k;
+  double* D3V = w.D3V + (size_t)b * rm * k;
+  const double* W1 = w.W1 + (size_t)b * n * n;
+  const double* E3 = w.E3 + (size_t)b * n * n;
+  const double* W3V = w.W3V + (size_t)b * rm * k;
+  const double* Q = w.Qb + (size_t)b * n * rm;
+  const double rho = w.rho, rho_f = w.rho_f, rx = w.relax, g = w.gamma;
+  // 1. cone + multiplicity part of the target
+  for (int e = tid; e < n * n; e += T) {
+    double y = Y[e];
+    tY[e] = rho_f * w.Ncnt[e] * y + rho * (rx * W1[e] + (1.0 - rx) * y + D1[e]) + rho * (y + (1.0 - rx) * D3[e] + rx * E3[e]);
+  }
+  for (int e = tid; e < r * k; e += T) {
+    int a = e % r, j = e / r;
+    tV[(size_t)j * rm + a] = rx * W3V[(size_t)j * rm + a] + (1.0 - rx) * Vt[(size_t)j * rm + a] + D3V[(size_t)j * rm + a];
+  }
+  for (int e = tid; e < R; e += T) mu[e] = lam[e] / rho;
+  __syncthreads();
+  // 2. + gamma/2 * sum_j E_j' alpha alpha' E_j   (columns sequentially: no write conflicts inside one column)
+  const double* alpha = w.alpha + (size_t)b * w.nnz;
+  for (int j = 0; j < m; ++j) {
+    const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
+    for (int e = tid; e < c * c; e += T) {
+      int p = e % c, q = e / c;
+      tY[(size_t)w.col_idx[off + q] * n + w.col_idx[off + p]] += 0.5 * g * alpha[off + p] * alpha[off + q];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < n * n; e += T) tY[e] /= (rho * w.wY1[e]);
+  for (int e = tid; e < n * k; e += T) {
+    int i = e % n, j = e / n;
+    double acc = 0.0;
+    for (int a = 0; a < r; ++a) acc += Q[(size_t)a * n + i] * tV[(size_t)j * rm + a];
+    tU[e] = acc;
+  }
+  __syncthreads();
+  // 3. c = A t - b
+  const double* cutx = w.cutx + (size_t)b * w.Lmax * n;
+  for (int rr = 0; rr < R; ++rr) {
+    const int kind = w.rkind[(size_t)b * w.Rmax + rr];
+    double acc = 0.0;
+    if (kind == ROW_TRACE) {
+      for (int i = tid; i < n; i += T) acc += tY[(size_t)i * n + i];
+    } else if (kind == ROW_BOX) {
+      if (tid == 0) acc = w.rcoef[((size_t)b * w.Rmax + rr) * k] * tU[(size_t)w.rbj[(size_t)b * w.Rmax + rr] * n + w.rbi[(size_t)b * w.Rmax + rr]];
+    } else {
+      const double* x = cutx + (size_t)w.rcut[(size_t)b * w.Rmax + rr] * n;
+      const double* cf = w.rcoef + ((size_t)b * w.Rmax + rr) * k;
+      if (kind == ROW_CUT) {
+        for (int e = tid; e < n * n; e += T) { int i = e % n, j = e / n; acc += x[i] * x[j] * tY[e]; }
+      }
+      for (int e = tid; e < n * k; e += T) { int i = e % n, j = e / n; if (cf[j] != 0.0) acc += cf[j] * x[i] * tU[e]; }
+    }
+    double tot = block_sum(acc, red);
+    if (tid == 0) cvec[rr] = tot - w.rrhs[(size_t)b * w.Rmax + rr];
+  }
+  __syncthreads();
+  // 4. multipliers (mu = lam / rho)
+  if (tid < WAVE) wave_nnqp(w.G + (size_t)b * w.Rmax * w.Rmax, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid);
+  __syncthreads();
+  for (int e = tid; e < R; e += T) lam[e] = rho * mu[e];
+  // 5. U-space correction  corr = A_U' mu / 2  (n x k, stored over tU)  and Vn = tV - Q' corr
+  for (int e = tid; e < n * k; e += T) {
+    int i = e % n, j = e / n;
+    double corr = 0.0;
+    for (int rr = 0; rr < R; ++rr) { double mv = mu[rr]; if (mv != 0.0) corr += mv * rowU_entry(w, b, rr, i, j); }
+    tU[e] = 0.5 * corr;
+  }
+  __syncthreads();
+  double rp2 = 0.0, rd2 = 0.0;
+  for (int e = tid; e < r * k; e += T) {
+    int a = e % r, j = e / r;
+    double qc = 0.0;
+    for (int i = 0; i < n; ++i) qc += Q[(size_t)a * n + i] * tU[(size_t)j * n + i];
+    const size_t ix = (size_t)j * rm + a;
+    double vn = tV[ix] - qc, vold = Vt[ix], w3 = W3V[ix];
+    D3V[ix] += rx * w3 + (1.0 - rx) * vold - vn;
+    rp2 += 2.0 * (w3 - vn) * (w3 - vn); rd2 += 2.0 * (vn - vold) * (vn - vold);
+    tV[ix] = vn;
+  }
+  for (int e = tid; e < k * k; e += T) {
+    double zi = ((e % k) == (e / k)) ? 1.0 : 0.0;
+    double w3t = w.W3T[(size_t)b * k * k + e];
+    w.D3T[(size_t)b * k * k + e] += rx * (w3t - zi);
+    rp2 += (w3t - zi) * (w3t - zi);
+  }
+  __syncthreads();
+  for (int e = tid; e < r * k; e += T) { int a = e % r, j = e / r; Vt[(size_t)j * rm + a] = tV[(size_t)j * rm + a]; }
+  for (int e = tid; e < n * k; e += T) {  // U = Q Vt (iterate in the subspace; a feasible U is recovered at the end)
+    int i = e % n, j = e / n;
+    double acc = 0.0;
+    for (int a = 0; a < r; ++a) acc += Q[(size_t)a * n + i] * tV[(size_t)j * rm + a];
+    U[e] = acc;
+  }
+  // 6. Y
+  for (int e = tid; e < n * n; e += T) {
+    int i = e % n, j = e / n;
+    if (i < j) continue;
+    double corr = 0.0;
+    for (int rr = 0; rr < R; ++rr) {
+      double mv = mu[rr];
+      if (mv == 0.0) continue;
+      int kind = w.rkind[(size_t)b * w.Rmax + rr];
+      if (kind == ROW_TRACE) { if (i == j) corr += mv; }
+      else if (kind == ROW_CUT) { const double* x = cutx + (size_t)w.rcut[(size_t)b * w.Rmax + rr] * n; corr += mv * x[i] * x[j]; }
+    }
+    const size_t a1 = (size_t)j * n + i, a2 = (size_t)i * n + j;
+    double t = 0.5 * (tY[a1] + tY[a2]);
+    double yn = t - corr / w.wY1[a1];
+    double yold = Y[a1];
+    double w1 = W1[a1], e3 = E3[a1], d3 = D3[a1];
+    double d1n = D1[a1] + rx * w1 + (1.0 - rx) * yold - yn;
+    double w3y = yold - d3 + e3;                       // projection output of the small-cone block
+    double d3n = (1.0 - rx) * d3 + yold + rx * e3 - yn;
+    D1[a1] = d1n; D1[a2] = d1n; D3[a1] = d3n; D3[a2] = d3n;
+    double mult = (i == j) ? 1.0 : 2.0;
+    rp2 += mult * ((w1 - yn) * (w1 - yn) + (w3y - yn) * (w3y - yn));
+    rd2 += mult * (yn - yold) * (yn - yold);
+    Yp[a1] = yold; Yp[a2] = yold; Y[a1] = yn; Y[a2] = yn;
+  }
+  rp2 = block_sum(rp2, red);
+  rd2 = block_sum(rd2, red);
+  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.iters[b] += 1; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// certificate kernels
+//   k_check_build : Mchk = -gamma/2 Lx Lx' + sum_cut lam x x' - rho E3   (E3 = Q Q3_11 Q' from the last k_small)
+//                   cpen = sum_j || Q'(sum_r lam_r CU_r)_j - 2 rho Q3V_j || ;  cst = -sum_{r != trace} lam_r rhs_r - rho tr(Q3T)
+//   (k_cone CONE_EVALS then fills evsum)
+//   k_check_final : lb = c0 + evsum - cpen + cst ; stop tests (gap, infeasibility, stall)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
+  __shared__ double red[32];
+  extern __shared__ double smem[];   // n*k doubles: cU
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b]) return;
+  const int n = w.n, k = w.k, m = w.m, R = w.R[b], rm = w.rmax, r = w.rr[b];
+  double* M = w.Mchk + (size_t)b * n * n;
+  const double* E3 = w.E3 + (size_t)b * n * n;
+  const double* lam = w.lam + (size_t)b * w.Rmax;
+  const double* cutx = w.cutx + (size_t)b * w.Lmax * n;
+  const double* Q = w.Qb + (size_t)b * n * rm;
+  const double rho = w.rho, g = w.gamma;
+  double* cU = w.chk_scratch + (size_t)b * n * k;
+  for (int e = tid; e < n * n; e += T) {
+    int i = e % n, j = e / n;
+    double v = -rho * E3[e];
+    for (int rr = 0; rr < R; ++rr) {
+      double lv = lam[rr];
+      if (lv != 0.0 && w.rkind[(size_t)b * w.Rmax + rr] == ROW_CUT) {
+        const double* x = cutx + (size_t)w.rcut[(size_t)b * w.Rmax + rr] * n;
+        v += lv * x[i] * x[j];
+      }
+    }
+    M[e] = v;
+  }
+  for (int e = tid; e < n * k; e += T) {
+    int i = e % n, j = e / n;
+    double cu = 0.0;
+    for (int rr = 0; rr < R; ++rr) { double lv = lam[rr]; if (lv != 0.0) cu += lv * rowU_entry(w, b, rr, i, j); }
+    cU[e] = cu;
+  }
+  __syncthreads();
+  const double* al = w.alphaX + (size_t)b * w.nnz;
+  for (int j = 0; j < m; ++j) {
+    const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
+    for (int e = tid; e < c * c; e += T) {
+      int p = e % c, q = e / c;
+      M[(size_t)w.col_idx[off + q] * n + w.col_idx[off + p]] -= 0.5 * g * al[off + p] * al[off + q];
+    }
+    __syncthreads();
+  }
+  double pen = 0.0;
+  for (int j = 0; j < k; ++j) {
+    double acc = 0.0;
+    for (int a = tid; a < r; a += T) {
+      double cv = -2.0 * rho * w.Q3V[(size_t)b * rm * k + (size_t)j * rm + a];
+      for (int i = 0; i < n; ++i) cv += Q[(size_t)a * n + i] * cU[(size_t)j * n + i];
+      acc += cv * cv;
+    }
+    pen += sqrt(block_sum(acc, red));
+  }
+  if (tid == 0) {
+    double cst = 0.0;
+    for (int rr = 0; rr < R; ++rr)
+      if (w.rkind[(size_t)b * w.Rmax + rr] != ROW_TRACE) cst -= lam[rr] * w.rrhs[(size_t)b * w.Rmax + rr];
+    for (int j = 0; j < k; ++j) cst -= rho * w.Q3T[(size_t)b * k * k + (size_t)j * k + j];
+    w.cpen[b] = pen; w.cst[b] = cst;
+  }
+}
+
+__global__ void k_check_final(OmcWS w, int last) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= w.B || w.done[b]) return;
+  double lbv = w.c0[b] + w.evsum[b] - w.cpen[b] + w.cst[b];
+  if (lbv > w.lb[b]) w.lb[b] = lbv;
+  const double obj = w.obj[b];
+  w.objout[b] = obj;
+  const double Nk = (double)(w.n + w.k);
+  const bool feas = w.rp[b] <= w.eps_feas * sqrt(Nk);
+  if ((obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && feas) { w.done[b] = 1; w.status[b] = OMC_ST_OPTIMAL; return; }
+  // f(Y) <= f(0) = 1/2 ||A_Omega||^2 on the feasible set: a larger certified bound proves infeasibility
+  if (w.lb[b] > 0.5 * w.sumA2 * (1.0 + 1e-9) + 1e-9) { w.done[b] = 1; w.status[b] = OMC_ST_INFEASIBLE; return; }
+  // stationary primal value and no progress of the bound: give up with values (MOI.SLOW_PROGRESS)
+  if (fabs(obj - w.objprev[b]) <= 1e-8 * fmax(1.0, fabs(obj)) && lbv <= w.lbprev[b] + 1e-8 * fmax(1.0, fabs(obj))) w.stall[b] += 1;
+  else w.stall[b] = 0;
+  w.objprev[b] = obj; w.lbprev[b] = w.lb[b];
+  if (w.stall[b] >= w.stall_checks) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }
+  if (last) { w.done[b] = 1; w.status[b] = last; }
+}
+
+__global__ void k_zero_check(OmcWS w) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= w.B || w.done[b]) return;
+  w.obj[b] = 0.0; w.c0[b] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// outputs: X = gamma * Y * Lx (n x m), Theta = gamma * Lx' X (m x m)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_make_X(OmcWS w, double* X) {
+  const int b = blockIdx.y, n = w.n, m = w.m;
+  const double* Y = w.Y + (size_t)b * n * n;
+  const double* al = w.alphaX + (size_t)b * w.nnz;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * m; e += gridDim.x * blockDim.x) {
+    int i = e % n, j = e / n;
+    const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
+    double acc = 0.0;
+    for (int p = 0; p < c; ++p) acc += Y[(size_t)w.col_idx[off + p] * n + i] * al[off + p];
+    X[(size_t)b * n * m + e] = w.gamma * acc;
+  }
+}
+__global__ void k_make_Theta(OmcWS w, const double* X, double* Th) {
+  const int b = blockIdx.y, n = w.n, m = w.m;
+  const double* al = w.alphaX + (size_t)b * w.nnz;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m * m; e += gridDim.x * blockDim.x) {
+    int i = e % m, j = e / m;  // Theta[i][j] = gamma * sum_p Lx[p,i] X[p,j]
+    const int off = w.col_ptr[i], c = w.col_ptr[i + 1] - off;
+    double acc = 0.0;
+    for (int p = 0; p < c; ++p) acc += al[off + p] * X[(size_t)b * n * m + (size_t)j * n + w.col_idx[off + p]];
+    Th[(size_t)b * m * m + e] = w.gamma * acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// evaluate_objective (OMC.jl:2352-2358): one workgroup per matrix, coalesced column-major sweep
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_eval_objective(int n, int m, double gamma, const double* A, const uint8_t* mask,
+                                                       const double* X, double* out) {
+  __shared__ double red[32];
+  const int b = blockIdx.x;
+  const double* Xb = X + (size_t)b * n * m;
+  double fit = 0.0, reg = 0.0;
+  for (int e = threadIdx.x; e < n * m; e += blockDim.x) {
+    double x = Xb[e];
+    reg += x * x;
+    if (mask[e]) { double d = x - A[e]; fit += d * d; }
+  }
+  fit = block_sum(fit, red);
+  reg = block_sum(reg, red);
+  if (threadIdx.x == 0) out[b] = 0.5 * fit + reg / (2.0 * gamma);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+void omc_launch_setup(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(w->B), dim3(256), 0, s, *w); }
+void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s) {
+  const int wpb = 4;
+  const int waves = w->B * w->m;
+  const int blocks = (waves + wpb - 1) / wpb;
+  hipLaunchKernelGGL(k_colprox, dim3(blocks), dim3(wpb * 64), (size_t)wpb * w->cp_lds_doubles * sizeof(double), s, *w, mode);
+}
+void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
+  if (use_lds) hipLaunchKernelGGL(k_cone<true>, dim3(w->B), dim3(512), lds_bytes, s, *w, mode);
+  else hipLaunchKernelGGL(k_cone<false>, dim3(w->B), dim3(512), 0, s, *w, mode);
+}
+void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
+  if (use_lds) hipLaunchKernelGGL(k_small<true>, dim3(w->B), dim3(256), lds_bytes, s, *w, mode);
+  else hipLaunchKernelGGL(k_small<false>, dim3(w->B), dim3(256), 0, s, *w, mode);
+}
+void omc_launch_global(const OmcWS* w, int use_lds, size_t lds_bytes, hipStream_t s) {
+  if (use_lds) hipLaunchKernelGGL(k_global<true>, dim3(w->B), dim3(512), lds_bytes, s, *w);
+  else hipLaunchKernelGGL(k_global<false>, dim3(w->B), dim3(512), 0, s, *w);
+}
+void omc_launch_check_zero(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_zero_check, dim3((w->B + 63) / 64), dim3(64), 0, s, *w); }
+void omc_launch_check_build(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_check_build, dim3(w->B), dim3(512), 0, s, *w); }
+void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s) {
+  hipLaunchKernelGGL(k_check_final, dim3((w->B + 63) / 64), dim3(64), 0, s, *w, last);
+}
+void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s) { hipLaunchKernelGGL(k_make_X, dim3(64, w->B), dim3(256), 0, s, *w, X); }
+void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s) {
+  hipLaunchKernelGGL(k_make_Theta, dim3(64, w->B), dim3(256), 0, s, *w, X, Th);
+}
+void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,
+                               double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_eval_objective, dim3(B), dim3(256), 0, s, n, m, gamma, A, mask, X, out);
+}
+int omc_set_max_lds(void) {
+  hipError_t e1 = hipFuncSetAttribute((const void*)k_cone<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  hipError_t e2 = hipFuncSetAttribute((const void*)k_global<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  hipError_t e3 = hipFuncSetAttribute((const void*)k_colprox, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  hipError_t e4 = hipFuncSetAttribute((const void*)k_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  if (e1 != hipSuccess) return 1000 + (int)e1;
+  if (e2 != hipSuccess) return 2000 + (int)e2;
+  if (e3 != hipSuccess) return 3000 + (int)e3;
+  if (e4 != hipSuccess) return 4000 + (int)e4;
+  return 0;
+}
+}

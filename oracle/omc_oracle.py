@@ -434,14 +434,18 @@ def build_rows(inst, cuts, cut_type, U_lower=None, U_upper=None, reference_quirk
 @dataclass
 class RelaxParams:
     eps_gap: float = 1e-6        # stop when (objective - dual_bound) <= eps_gap * max(1,|objective|) ...
-    eps_feas: float = 1e-7       # ... and the cone residual ||W - Z||_F <= eps_feas * sqrt(n+k)
+    eps_feas: float = 1e-7       # ... and the cone residual rp <= eps_feas * sqrt(n+k)
     max_iters: int = 5000
     check_every: int = 25
-    rho_scale: float = 1.0       # rho = rho_scale * gamma/2 * ||A_Omega||^2 / m
+    rho_scale: float = 1.0       # rho_0 = rho_scale * gamma/2 * ||A_Omega||^2 / (m (1 + gamma k/n)^2)
     rho_f_ratio: float = 0.1     # rho of the per-column blocks relative to the cone blocks
     relax: float = 1.6           # over-relaxation
+    adapt: int = 0               # 1: residual balancing of rho at check points (first adapt_until iterations)
+    adapt_until: int = 1500
+    stall_checks: int = 8        # stop with SLOW_PROGRESS when the objective is stationary for this many checks
     time_limit: float = 3600.0
     reference_quirk_q1: bool = True
+    rho_init: float = 0.0        # > 0: start from this penalty (e.g. the parent's final rho)
 
 
 def _prox_columns(inst, Yx, alpha, svals, rho_f):
@@ -487,31 +491,60 @@ def _prox_columns(inst, Yx, alpha, svals, rho_f):
     return out, sout, LL
 
 
-def dual_bound_from(inst, Lam, rows, lam, Psi, Psi2):
-    """Valid lower bound on the relaxation optimum for ANY Lam (support in Omega), lam >= 0, Psi >= 0, Psi2 >= 0.
+def row_subspace(rows, n, k, tol=1e-10):
+    """Orthonormal basis Q (n x r) of the span of every U-functional used by the rows (cut vectors x_l and
+    the coordinate vectors of non-default box entries).  Only v = X'U enters the rows, so the order-(n+k)
+    cone [Y U;U' I] >= 0 is equivalent to Y >= 0 plus the order-(r+k) cone [Q'YQ  Q'U; U'Q  I] >= 0
+    (Schur complement; U = Y Q (Q'YQ)^+ Q'U recovers a U with U U' <= Y and the same X'U)."""
+    cols = []
+    for r in range(len(rows)):
+        if rows.kinds[r] == "trace":
+            continue
+        CU = rows.CU[r]
+        for j in range(k):
+            if np.abs(CU[:, j]).max() > 0:
+                cols.append(CU[:, j] / np.linalg.norm(CU[:, j]))
+    if not cols:
+        return np.zeros((n, 0))
+    # modified Gram-Schmidt with re-orthogonalisation, in row order (the HIP host code does the same)
+    Q = []
+    for c in cols:
+        v = c.copy()
+        for _ in range(2):
+            for q in Q:
+                v -= (q @ v) * q
+        nv = np.linalg.norm(v)
+        if nv > tol:
+            Q.append(v / nv)
+    return np.stack(Q, 1) if Q else np.zeros((n, 0))
+
+
+def dual_bound_from(inst, Lam, rows, lam, Q, Psi3):
+    """Valid lower bound on the relaxation optimum for ANY Lam (support in Omega), lam >= 0, Psi3 >= 0.
 
     f(Y) >= <A,Lam> - 1/2||Lam||^2 - gamma/2 <Y, Lam Lam'>        (Fenchel; equality at Lam = alpha(Y))
-    L    =  <G,Y> + sum_r lam_r (row_r - rhs_r) - <Psi, [Y U;U' I]> - <Psi2, I - Y>
-    min over the simple superset {0<=Y<=I, trY<=k} x {||U_j||<=1}  (both implied by the constraints):
-        sum_{i<=k} min(eig_i(M),0) - sum_j ||cU_j|| + const.
+    L    =  <G,Y> + sum_r lam_r (row_r - rhs_r) - <Psi3, [Q'YQ Vt; Vt' I]>,     Vt = Q'U
+    minimised over the simple superset {0<=Y<=I, trY<=k} x {||Vt_j||<=1} (both implied by the constraints):
+        sum_{i<=k} min(eig_i(M),0) - sum_j ||c_j|| + const.
     """
     n, k, g = inst.n, inst.k, inst.gamma
+    r = Q.shape[1]
     c0 = float((inst.A * Lam).sum()) - 0.5 * float((Lam * Lam).sum())
     M = -0.5 * g * (Lam @ Lam.T)
     cU = np.zeros((n, k)); const = 0.0
-    for r in range(len(rows)):
-        if rows.kinds[r] == "trace" or lam[r] == 0.0:
+    for rr in range(len(rows)):
+        if rows.kinds[rr] == "trace" or lam[rr] == 0.0:
             continue                               # trace is kept in the simple set
-        if rows.kinds[r] == "cut":
-            x = rows.xs[r]
-            M += lam[r] * np.outer(x, x)
-        cU += lam[r] * rows.CU[r]
-        const -= lam[r] * rows.rhs[r]
-    M -= Psi[:n, :n]; cU -= 2.0 * Psi[:n, n:]; const -= float(np.trace(Psi[n:, n:]))
-    if Psi2 is not None:
-        M += Psi2; const -= float(np.trace(Psi2))
+        if rows.kinds[rr] == "cut":
+            x = rows.xs[rr]
+            M += lam[rr] * np.outer(x, x)
+        cU += lam[rr] * rows.CU[rr]
+        const -= lam[rr] * rows.rhs[rr]
+    M -= Q @ Psi3[:r, :r] @ Q.T
+    cV = Q.T @ cU - 2.0 * Psi3[:r, r:]
+    const -= float(np.trace(Psi3[r:, r:]))
     ev = np.linalg.eigvalsh(0.5 * (M + M.T))
-    return c0 + float(np.minimum(ev[:k], 0.0).sum()) - float(np.linalg.norm(cU, axis=0).sum()) + const
+    return c0 + float(np.minimum(ev[:k], 0.0).sum()) - float(np.linalg.norm(cV, axis=0).sum()) + const
 
 
 def primal_residuals(inst, rows, Y, U, X, Theta):
@@ -538,11 +571,38 @@ def primal_residuals(inst, rows, Y, U, X, Theta):
     return res
 
 
+ADAPT_AT = (50, 100, 150, 200, 300, 400, 600, 800, 1200, 1600)
+
+
+def initial_rho(inst, p):
+    g, n, m, k = inst.gamma, inst.n, inst.m, inst.k
+    if p.rho_init > 0:
+        return p.rho_init
+    rho = p.rho_scale * 0.5 * g * inst.sumA2 / (m * (1.0 + g * k / n) ** 2)
+    return rho if rho > 0 else 1.0
+
+
+def recover_U(Y, Q, Vt):
+    """U = Y Q (Q'YQ)^+ Vt : satisfies U U' <= Y and Q'U = Vt whenever [Q'YQ Vt; Vt' I] >= 0."""
+    n = Y.shape[0]
+    if Q.shape[1] == 0:
+        return np.zeros((n, Vt.shape[1]))
+    S = Q.T @ Y @ Q
+    w, V = np.linalg.eigh(0.5 * (S + S.T))
+    keep = w > 1e-12 * max(1.0, w[-1])
+    Sp = (V[:, keep] / w[keep]) @ V[:, keep].T
+    return Y @ (Q @ (Sp @ Vt))
+
+
 def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None, params=None,
                    warm=None, want_certificate=True):
     """matrix_completion_SDP_relaxation restated (disjunctive mode, no Shor).  Returns a dict with the
     reference's keys (objective, Y, U, X, Θ->"Theta", feasible, termination_status, solve_time) plus
-    dual_bound, iters, residuals and the warm-start state."""
+    dual_bound, iters, residuals and the warm-start state.
+
+    Consensus ADMM on (Y, U = Q Vt):  blocks (F) columns, (C1) 0 <= Y <= I, (C3) [Q'YQ Vt;Vt' I] >= 0,
+    global step = weighted projection on the linear rows.  Scaled duals D1, D3 (n x n), D3V (r x k), D3T (k x k).
+    """
     if cut_type not in CUT_TYPES:
         raise ValueError("Invalid input for disjunctive cuts type (OMC.jl:1456-1462)")
     p = params or RelaxParams()
@@ -550,84 +610,114 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
     n, m, k, g = inst.n, inst.m, inst.k, inst.gamma
     rows = build_rows(inst, cuts, cut_type, U_lower, U_upper, p.reference_quirk_q1)
     R = len(rows)
-    rho = p.rho_scale * 0.5 * g * inst.sumA2 / m
-    rho_f = rho * p.rho_f_ratio
-    ncone = 2 if k > 1 else 1
-    wY = rho_f * inst.N + rho * ncone
-    wU = 2.0 * rho * np.ones((n, k))
-    # Gram matrix of the rows in the metric of the consensus weights
+    Q = row_subspace(rows, n, k)
+    r = Q.shape[1]
+    rho = initial_rho(inst, p)
+    wY1 = p.rho_f_ratio * inst.N + 2.0            # weights for rho = 1
     AY = np.zeros((R, n * n)); AU = np.zeros((R, n * k)); b = np.array(rows.rhs)
-    for r in range(R):
-        if rows.kinds[r] == "trace":
-            AY[r] = np.eye(n).ravel()
-        elif rows.kinds[r] == "cut":
-            AY[r] = np.outer(rows.xs[r], rows.xs[r]).ravel()
-        AU[r] = rows.CU[r].ravel()
-    G = (AY / wY.ravel()) @ AY.T + (AU / wU.ravel()) @ AU.T
-
+    for rr in range(R):
+        if rows.kinds[rr] == "trace":
+            AY[rr] = np.eye(n).ravel()
+        elif rows.kinds[rr] == "cut":
+            AY[rr] = np.outer(rows.xs[rr], rows.xs[rr]).ravel()
+        AU[rr] = rows.CU[rr].ravel()
+    G1 = (AY / wY1.ravel()) @ AY.T + (AU / 2.0) @ AU.T          # Gram matrix for rho = 1
     if warm is not None:
-        Y = warm["Y"].copy(); U = warm["U"].copy(); Yp = warm.get("Yp", Y).copy()
+        Y = warm["Y"].copy(); Vt = Q.T @ warm["U"]; Yp = warm.get("Yp", Y).copy()
         alpha = [a.copy() for a in warm["alpha"]]; svals = list(warm["svals"])
-        D1 = warm["D1"].copy(); D2 = warm["D2"].copy()
+        D1 = warm["D1"].copy(); D3 = warm["D3"].copy()
+        rho = warm.get("rho", rho) if p.rho_init <= 0 else rho
     else:
-        Y = np.eye(n) * (k / n); U = np.zeros((n, k)); Yp = Y.copy()
+        Y = np.eye(n) * (k / n); Vt = np.zeros((r, k)); Yp = Y.copy()
         alpha = [np.zeros_like(a) for (_, _, _, a) in inst.groups]; svals = [None] * len(inst.groups)
-        D1 = np.zeros((n + k, n + k)); D2 = np.zeros((n, n))
+        D1 = np.zeros((n, n)); D3 = np.zeros((n, n))
+    D3V = np.zeros((r, k)); D3T = np.zeros((k, k))
     Ik = np.eye(k)
     lam = np.zeros(R)
     status = OMC_SLOW_PROGRESS
     obj = math.inf; lb = -math.inf; rp = rd = math.inf
     hist = []
-    it = 0
+    it = 0; rx = p.relax
+    stall = 0; obj_prev = math.inf; lb_prev = -math.inf
+    Q3 = np.zeros((r + k, r + k))
     for it in range(1, p.max_iters + 1):
+        rho_f = rho * p.rho_f_ratio
         alpha, svals, LL = _prox_columns(inst, 2.0 * Y - Yp, alpha, svals, rho_f)
-        Zg = np.block([[Y, U], [U.T, Ik]])
-        w1, V1 = _psd_split(Zg - D1)
-        W1 = (V1 * np.maximum(w1, 0.0)) @ V1.T
-        W1r = p.relax * W1 + (1.0 - p.relax) * Zg
-        H1 = W1r + D1
-        tY = rho_f * (inst.N * Y) + 0.5 * g * LL + rho * H1[:n, :n]
-        if k > 1:
-            w2, V2 = _psd_split(Y - D2)
-            W2 = (V2 * np.minimum(w2, 1.0)) @ V2.T
-            W2r = p.relax * W2 + (1.0 - p.relax) * Y
-            tY += rho * (W2r + D2)
-        tY /= wY
-        tU = H1[:n, n:]
+        # (C1) spectral clip of Y - D1 to [0, 1]
+        w1, V1 = _psd_split(Y - D1)
+        W1 = (V1 * np.clip(w1, 0.0, 1.0)) @ V1.T
+        # (C3) small cone
+        Min = Y - D3
+        S_in = Q.T @ Min @ Q; V_in = Vt - D3V
+        M3 = np.block([[S_in, V_in], [V_in.T, Ik - D3T]])
+        w3, V3 = _psd_split(M3)
+        P3 = (V3 * np.maximum(w3, 0.0)) @ V3.T
+        Q3 = P3 - 0.5 * (M3 + M3.T)
+        dS = Q3[:r, :r]; W3V = P3[:r, r:]; W3T = P3[r:, r:]
+        # global target
+        tY = (rho_f * (inst.N * Y) + 0.5 * g * LL + rho * (rx * W1 + (1.0 - rx) * Y + D1)
+              + rho * (Y + (1.0 - rx) * D3 + rx * (Q @ dS @ Q.T))) / (rho * wY1)
+        tV = rx * W3V + (1.0 - rx) * Vt + D3V
+        tU = Q @ tV
         c = AY @ tY.ravel() + AU @ tU.ravel() - b
-        lam = nnqp(G, c)
-        Yn = tY - ((AY.T @ lam) / wY.ravel()).reshape(n, n)
-        Un = tU - ((AU.T @ lam) / wU.ravel()).reshape(n, k)
+        mu = nnqp(G1, c)                                  # multipliers / rho
+        lam = rho * mu
+        Yn = tY - ((AY.T @ mu) / wY1.ravel()).reshape(n, n)
         Yn = 0.5 * (Yn + Yn.T)
-        Zn = np.block([[Yn, Un], [Un.T, Ik]])
-        D1 = D1 + W1r - Zn
-        if k > 1:
-            D2 = D2 + W2r - Yn
-        rp = float(np.linalg.norm(W1 - Zn)); rd = float(np.linalg.norm(Zn - Zg))
-        Yp = Y; Y = Yn; U = Un
+        Vn = tV - Q.T @ ((AU.T @ mu) / 2.0).reshape(n, k)
+        D1 = D1 + rx * W1 + (1.0 - rx) * Y - Yn
+        D3 = (1.0 - rx) * D3 + Y + rx * (Q @ dS @ Q.T) - Yn
+        D3V = D3V + rx * W3V + (1.0 - rx) * Vt - Vn
+        D3T = D3T + rx * (W3T - Ik)
+        W3Y_minus_Yn = Min + Q @ dS @ Q.T - Yn
+        rp = math.sqrt(float(np.linalg.norm(W1 - Yn) ** 2 + np.linalg.norm(W3Y_minus_Yn) ** 2
+                             + 2.0 * np.linalg.norm(W3V - Vn) ** 2 + np.linalg.norm(W3T - Ik) ** 2))
+        rd = math.sqrt(float(np.linalg.norm(Yn - Y) ** 2 + 2.0 * np.linalg.norm(Vn - Vt) ** 2))
+        Yp = Y; Y = Yn; Vt = Vn
         if it % p.check_every == 0 or it == p.max_iters:
             obj, Lam = inst.f_value(Y, want=True)
-            Psi = _proj_psd(rho * D1)
-            Psi2 = _proj_psd(-rho * D2) if k > 1 else None
-            lb = max(lb, dual_bound_from(inst, Lam, rows, lam, Psi, Psi2))
-            hist.append((it, obj, lb, rp, rd))
+            lb_new = dual_bound_from(inst, Lam, rows, lam, Q, rho * Q3)
+            lb = max(lb, lb_new)
+            hist.append((it, obj, lb, rp, rd, rho))
             if (obj - lb) <= p.eps_gap * max(1.0, abs(obj)) and rp <= p.eps_feas * math.sqrt(n + k):
                 status = OMC_OPTIMAL
                 break
+            if lb > 0.5 * inst.sumA2 * (1.0 + 1e-9) + 1e-9:   # f(Y) <= f(0) = 1/2||A_Omega||^2 for feasible Y
+                status = OMC_INFEASIBLE
+                break
+            if abs(obj - obj_prev) <= 1e-8 * max(1.0, abs(obj)) and lb_new <= lb_prev + 1e-8 * max(1.0, abs(obj)):
+                stall += 1
+            else:
+                stall = 0
+            obj_prev = obj; lb_prev = lb
+            if stall >= p.stall_checks:
+                break                                                  # SLOW_PROGRESS, values available
             if time.time() - t0 > p.time_limit:
                 status = OMC_TIME_LIMIT
                 break
+            if p.adapt and it in ADAPT_AT:
+                # residual balancing (normalised as in OSQP): primal rp / ||z||  vs  dual rho*rd / ||gradient scale||
+                zn = math.sqrt(float(np.linalg.norm(Y) ** 2 + 2.0 * np.linalg.norm(Vt) ** 2 + k))
+                dn = rho * math.sqrt(float(np.linalg.norm(D1) ** 2 + np.linalg.norm(D3) ** 2
+                                           + 2.0 * np.linalg.norm(D3V) ** 2 + np.linalg.norm(D3T) ** 2))
+                gn = max(dn, 0.5 * g * float(np.linalg.norm(LL)))
+                if gn > 0 and rd > 0 and rp > 0:
+                    ratio = (rp / zn) / (rho * rd / gn)
+                    if ratio > 2.0 or ratio < 0.5:
+                        fac = min(10.0, max(0.1, math.sqrt(ratio)))
+                        rho *= fac
+                        D1 /= fac; D3 /= fac; D3V /= fac; D3T /= fac
     obj, Lam = inst.f_value(Y, want=True)
     X = inst.X_of(Y, Lam)
-    out = dict(objective=obj, dual_bound=lb, Y=Y, U=U, X=X, termination_status=status, feasible=True,
-               solve_time=time.time() - t0, iters=it, rows=rows, lam=lam, hist=hist, rp=rp, rd=rd, rho=rho,
-               warm=dict(Y=Y, U=U, Yp=Yp, alpha=alpha, svals=svals, D1=D1, D2=D2))
+    U = recover_U(Y, Q, Vt)
+    out = dict(objective=obj, dual_bound=lb, Y=Y, U=U, X=X, termination_status=status,
+               feasible=status != OMC_INFEASIBLE, solve_time=time.time() - t0, iters=it, rows=rows, lam=lam,
+               hist=hist, rp=rp, rd=rd, rho=rho, Q=Q, Vt=Vt,
+               warm=dict(Y=Y, U=Q @ Vt, Yp=Yp, alpha=alpha, svals=svals, D1=D1, D3=D3, rho=rho))
     if want_certificate:
-        # Theta = X' pinv(Y) X is the minimal Theta with [Y X; X' Theta] >= 0; tr(Theta)/(2 gamma) closes f(Y).
-        wy, Vy = np.linalg.eigh(Y)
-        keep = wy > 1e-12 * max(1.0, wy[-1])
-        Yp_inv = (Vy[:, keep] / wy[keep]) @ Vy[:, keep].T
-        Theta = X.T @ Yp_inv @ X
+        # Theta = X' pinv(Y) X = gamma * Lam' X is the minimal Theta with [Y X; X' Theta] >= 0
+        Theta = g * (Lam.T @ X)
+        Theta = 0.5 * (Theta + Theta.T)
         out["Theta"] = Theta
         out["objective_reference_formula"] = compute_SDP_relaxation_objective(X, Theta, inst.A, inst.indices, g)
         out["residuals"] = primal_residuals(inst, rows, Y, U, X, Theta)
