@@ -64,7 +64,7 @@ typedef struct omc_instance omc_instance; /* opaque handle: device copies of A, 
 typedef struct omc_relax_params {
   double eps_gap;      /* stop when objective - dual_bound <= eps_gap * max(1,|objective|)   (1e-6)  */
   double eps_feas;     /* and cone residual <= eps_feas * sqrt(n+k)                          (1e-7)  */
-  int max_iters;       /* iteration cap -> OMC_SLOW_PROGRESS                                 (5000)  */
+  int max_iters;       /* iteration cap -> OMC_SLOW_PROGRESS                                 (3000)  */
   int check_every;     /* certificate evaluated every this many iterations                   (25)    */
   double rho_scale;    /* penalty = rho_scale * gamma/2 ||A_Omega||^2 / (m (1+gamma k/n)^2)  (1.0)   */
   double rho_f_ratio;  /* penalty of the per-column blocks relative to the cone blocks       (0.1)   */

@@ -81,7 +81,7 @@ int omc_device_count(void) {
 }
 
 void omc_relax_params_default(omc_relax_params* p) {
-  p->eps_gap = 1e-6; p->eps_feas = 1e-7; p->max_iters = 5000; p->check_every = 25;
+  p->eps_gap = 1e-6; p->eps_feas = 1e-7; p->max_iters = 3000; p->check_every = 25;
   p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
 }

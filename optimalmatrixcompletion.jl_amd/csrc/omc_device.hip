@@ -1027,7 +1027,7 @@ __global__ void k_check_final(OmcWS w, int last) {
   // f(Y) <= f(0) = 1/2 ||A_Omega||^2 on the feasible set: a larger certified bound proves infeasibility
   if (w.lb[b] > 0.5 * w.sumA2 * (1.0 + 1e-9) + 1e-9) { w.done[b] = 1; w.status[b] = OMC_ST_INFEASIBLE; return; }
   // stationary primal value and no progress of the bound: give up with values (MOI.SLOW_PROGRESS)
-  if (fabs(obj - w.objprev[b]) <= 1e-8 * fmax(1.0, fabs(obj)) && lbv <= w.lbprev[b] + 1e-8 * fmax(1.0, fabs(obj))) w.stall[b] += 1;
+  if (fabs(obj - w.objprev[b]) <= 1e-7 * fmax(1.0, fabs(obj)) && lbv <= w.lbprev[b] + 1e-7 * fmax(1.0, fabs(obj))) w.stall[b] += 1;
   else w.stall[b] = 0;
   w.objprev[b] = obj; w.lbprev[b] = w.lb[b];
   if (w.stall[b] >= w.stall_checks) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }

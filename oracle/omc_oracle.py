@@ -435,7 +435,7 @@ def build_rows(inst, cuts, cut_type, U_lower=None, U_upper=None, reference_quirk
 class RelaxParams:
     eps_gap: float = 1e-6        # stop when (objective - dual_bound) <= eps_gap * max(1,|objective|) ...
     eps_feas: float = 1e-7       # ... and the cone residual rp <= eps_feas * sqrt(n+k)
-    max_iters: int = 5000
+    max_iters: int = 3000
     check_every: int = 25
     rho_scale: float = 1.0       # rho_0 = rho_scale * gamma/2 * ||A_Omega||^2 / (m (1 + gamma k/n)^2)
     rho_f_ratio: float = 0.1     # rho of the per-column blocks relative to the cone blocks
@@ -685,7 +685,7 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
             if lb > 0.5 * inst.sumA2 * (1.0 + 1e-9) + 1e-9:   # f(Y) <= f(0) = 1/2||A_Omega||^2 for feasible Y
                 status = OMC_INFEASIBLE
                 break
-            if abs(obj - obj_prev) <= 1e-8 * max(1.0, abs(obj)) and lb_new <= lb_prev + 1e-8 * max(1.0, abs(obj)):
+            if abs(obj - obj_prev) <= 1e-7 * max(1.0, abs(obj)) and lb_new <= lb_prev + 1e-7 * max(1.0, abs(obj)):
                 stall += 1
             else:
                 stall = 0

@@ -1,0 +1,81 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/omc.h declares, and fails
+loudly (no CPU fallback) when no GPU is visible.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "omc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(omc_[A-Za-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(omc):
+    lib = omc.load()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for s in names:
+        assert hasattr(lib, s), f"{s} declared in include/omc.h but not exported"
+    assert set(omc.EXPORTS) <= set(names)
+    assert lib.omc_version() == 100
+
+
+def test_params_default_and_struct_layout(omc):
+    p = omc.default_params()
+    assert (p.eps_gap, p.eps_feas, p.max_iters, p.check_every) == (1e-6, 1e-7, 3000, 25)
+    assert (p.rho_scale, p.rho_f_ratio, p.relax) == (1.0, 0.1, 1.6)
+    assert p.reference_quirk_q1 == 1 and p.breakpoints == 1 and p.stall_checks == 8
+    with pytest.raises(TypeError):
+        omc.default_params(not_a_field=1)
+
+
+def test_no_cpu_fallback(omc):
+    """On a box without a GPU the engine must refuse to construct (OMC_ERR_NO_DEVICE), never silently compute on CPU."""
+    lib = omc.load()
+    if lib.omc_device_count() > 0:
+        pytest.skip("GPU present")
+    A = np.zeros((4, 5)); mask = np.ones((4, 5), bool)
+    with pytest.raises(omc.OmcError) as e:
+        omc.Engine(A, mask, 80.0, 1)
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_argument_checks_mirror_reference_errors(omc):
+    lib = omc.load()
+    h = C.c_void_p()
+    A = np.zeros((5, 3)); mask = np.ones((5, 3), np.uint8)
+    # n <= m required (OMC.jl:249-254) -- checked before any device call
+    rc = lib.omc_instance_create(5, 3, 1, A.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p), 80.0, 0, C.byref(h))
+    assert rc == -2 and b"n <= m" in lib.omc_last_error()
+    rc = lib.omc_instance_create(3, 5, 1, None, None, 80.0, 0, C.byref(h))
+    assert rc == -3
+    rc = lib.omc_instance_create(3, 5, 0, A.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p), 80.0, 0, C.byref(h))
+    assert rc == -3
+    assert lib.omc_relax_solve(None) == -3
+    with pytest.raises(ValueError):
+        omc.Engine(np.zeros((3, 4)), np.ones((3, 5), bool), 80.0, 1)       # size(A) == size(indices) (OMC.jl:240-246)
+
+
+def test_host_side_helpers(omc):
+    bnb = omc.pkg.bnb; data = omc.pkg.data
+    assert bnb.child_directions("linear", 2) == [["left", "left"], ["right", "left"], ["left", "right"], ["right", "right"]]
+    A, mask = data.generate_matrix_completion_data(1, 10, 12, 40, seed=0)
+    assert mask.sum() == 40 and mask.any(0).all() and mask.any(1).all()
+    A2, mask2 = data.generate_matrix_completion_data(1, 10, 12, 40, seed=0)
+    assert data.instance_sha256(A, mask) == data.instance_sha256(A2, mask2)
+    with pytest.raises(ValueError):
+        data.generate_matrix_completion_data(1, 12, 10, 40, seed=0)
+    with pytest.raises(ValueError):
+        data.generate_matrix_completion_data(2, 10, 12, 30, seed=0)        # under-determined (utils.jl:85-90)
+    nodes = list(range(10))
+    assert bnb.shard_nodes(nodes, 1, 4) == [1, 5, 9]
+    assert sorted(sum((bnb.shard_nodes(nodes, r, 3) for r in range(3)), [])) == nodes
+    x = np.arange(4.0); U = np.ones((4, 1))
+    kids = bnb.make_children([("c0",)], dict(breakpoint_vec=x, U=U), "linear", 1)
+    assert len(kids) == 2 and kids[0][0] == ("c0",) and kids[1][-1][2] == ["right"]

@@ -1,0 +1,167 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).  Everything goes through the C ABI (ctypes), the
+checker is the CPU oracle on the same seeded inputs.  Tolerances: the relaxation objective is compared at 2e-6
+relative (both sides certify their value within 1e-6 of the optimum of the convex program); plain kernels
+(objective scan, eigen-oracle) at 1e-12 / 1e-8."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GAMMA = 80.0
+OBJ_REL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def have_gpu(omc):
+    lib = omc.load()
+    if lib.omc_device_count() < 1:
+        pytest.fail("no HIP device: GPU tests must run on the MI355X box (the HIP path has no CPU fallback)")
+    return True
+
+
+def oracle_path(orc, inst, cut_type, depth, rho_scale, seed):
+    rng = np.random.default_rng(seed)
+    dirs = orc.child_directions(cut_type, inst.k)
+    cuts = []; nodes = [[]]
+    for d in range(depth):
+        r = orc.sdp_relaxation(inst, cuts, cut_type, params=orc.RelaxParams(rho_scale=rho_scale), want_certificate=False)
+        x, _ = orc.breakpoint_vector(r["Y"], r["U"])
+        vhat = r["U"].T @ x
+        ok = [d_ for d_ in dirs if all((abs(vhat[j]) > 0.05) or (d_[j] in ("left", "right")) for j in range(inst.k))]
+        cuts = cuts + [(x, r["U"].copy(), ok[int(rng.integers(len(ok)))])]
+        nodes.append(list(cuts))
+    return nodes
+
+
+@pytest.mark.parametrize("n,m,k,kind,cut_type,rho_scale,depth", [
+    (12, 15, 1, "readme", "linear", 8.0, 2),
+    (20, 25, 1, "readme", "linear", 16.0, 4),
+    (24, 30, 1, "lowrank", "linear2", 4.0, 3),
+    (24, 24, 1, "lowrank", "linear3", 4.0, 3),
+    (16, 20, 2, "lowrank", "linear", 4.0, 2),
+    (50, 50, 1, "readme", "linear", 8.0, 2),       # BASELINE config 1 shape
+])
+def test_relaxation_matches_oracle(have_gpu, omc, orc, n, m, k, kind, cut_type, rho_scale, depth):
+    A, mask = orc.make_instance(n, m, k, seed=21, kind=kind, n_indices=None if kind == "readme" else int(0.35 * n * m))
+    inst = orc.Instance(A, mask, GAMMA, k)
+    nodes = oracle_path(orc, inst, cut_type, depth, rho_scale, seed=3)
+    ref = [orc.sdp_relaxation(inst, c, cut_type, params=orc.RelaxParams(rho_scale=rho_scale)) for c in nodes]
+    eng = omc.Engine(A, mask, GAMMA, k)
+    out = eng.matrix_completion_SDP_relaxation(nodes, cut_type, params=omc.default_params(rho_scale=rho_scale), want_Theta=True)
+    for g, r in zip(out, ref):
+        assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
+        assert g["status_code"] == r["termination_status"]
+        if g["status_code"] == 0:
+            assert g["objective"] - g["dual_bound"] <= 1.01e-6 * max(1.0, abs(g["objective"]))
+            assert g["dual_bound"] == pytest.approx(r["dual_bound"], rel=OBJ_REL)
+        # separation oracle (OMC.jl:2466-2477): eigenvalue and canonical-sign eigenvector of U U' - Y
+        S = g["U"] @ g["U"].T - g["Y"]
+        w, V = np.linalg.eigh(0.5 * (S + S.T))
+        assert g["lambda_min"][0] == pytest.approx(w[0], abs=1e-9)
+        if w[1] - w[0] > 1e-6:
+            v = V[:, 0] * np.sign(V[np.argmax(np.abs(V[:, 0])), 0])
+            assert np.allclose(g["breakpoint_vec"], v, atol=1e-6)
+        # the returned point is feasible for the reference's program (OMC.jl:1554-1685) and reproduces its objective
+        Theta = 0.5 * (g["Theta"] + g["Theta"].T)
+        res = orc.primal_residuals(inst, r["rows"], g["Y"], g["U"], g["X"], Theta)
+        assert res["max"] <= 2e-5 * max(1.0, np.abs(Theta).max()), res
+        assert orc.compute_SDP_relaxation_objective(g["X"], Theta, A, mask, GAMMA) == pytest.approx(g["objective"], rel=1e-8)
+    eng.close()
+
+
+def test_objective_scan_and_bitmatrix_constructor(have_gpu, omc, orc):
+    rng = np.random.default_rng(0)
+    n, m = 37, 53
+    A, mask = orc.make_instance(n, m, 1, seed=1, kind="readme")
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    Xs = rng.standard_normal((5, n, m))
+    got = eng.evaluate_objective(Xs)
+    ref = np.array([orc.evaluate_objective(x, A, mask, GAMMA) for x in Xs])
+    assert np.allclose(got, ref, rtol=1e-12)
+    with pytest.raises(ValueError):
+        eng.evaluate_objective(np.zeros((n, m + 1)))                      # OMC.jl:2337-2348
+    eng.close()
+    # Julia BitMatrix layout: packed UInt64 chunks, column-major, LSB first
+    bits = np.asfortranarray(mask).ravel(order="F")
+    chunks = np.zeros((bits.size + 63) // 64, dtype=np.uint64)
+    for e in np.flatnonzero(bits):
+        chunks[e >> 6] |= np.uint64(1) << np.uint64(e & 63)
+    lib = omc.load(); h = C.c_void_p(); Af = np.asfortranarray(A)
+    rc = lib.omc_instance_create_bits(n, m, 1, Af.ctypes.data_as(C.c_void_p), chunks.ctypes.data_as(C.c_void_p), GAMMA, 0, C.byref(h))
+    assert rc == 0
+    out = np.zeros(1); X0 = np.ascontiguousarray(np.asfortranarray(Xs[0]).ravel(order="F"))
+    assert lib.omc_evaluate_objective(h, 1, X0.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    assert out[0] == pytest.approx(ref[0], rel=1e-12)
+    lib.omc_instance_destroy(h)
+
+
+def test_separation_and_master_feasibility(have_gpu, omc, orc):
+    rng = np.random.default_rng(5)
+    n, m, k = 30, 32, 2
+    A, mask = orc.make_instance(n, m, k, seed=2, kind="lowrank", n_indices=400)
+    eng = omc.Engine(A, mask, GAMMA, k)
+    Ys, Us = [], []
+    for t in range(4):
+        B = rng.standard_normal((n, n)); Y = B @ B.T / n; U = rng.standard_normal((n, k)) * 0.2
+        Ys.append(Y); Us.append(U)
+    Q = np.linalg.qr(rng.standard_normal((n, k)))[0]
+    Ys.append(Q @ Q.T); Us.append(Q)                                     # master feasible: Y = U U'
+    for bp in ("smallest_1_eigvec", "smallest_2_eigvec"):
+        x, ev, fe = eng.breakpoint_vectors(Ys, Us, bp)
+        for b in range(5):
+            xr, evr = orc.breakpoint_vector(Ys[b], Us[b], bp)
+            assert np.allclose(ev[b], evr, atol=1e-10)
+            if b < 4:
+                assert np.allclose(x[b], xr, atol=1e-7)
+            assert bool(fe[b]) == orc.master_feasible(Ys[b], Us[b])[0]
+    assert eng.matrix_completion_master_feasible(Ys[4], Us[4]) and not eng.matrix_completion_master_feasible(Ys[0], Us[0])
+    with pytest.raises(ValueError):
+        eng.breakpoint_vectors(Ys, Us, "largest_eigvec")                 # OMC.jl:2440-2446
+    eng.close()
+
+
+def test_error_behaviour_and_edge_cases(have_gpu, omc, orc):
+    A, mask = orc.make_instance(10, 12, 1, seed=3, kind="readme")
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    with pytest.raises(ValueError):
+        eng.matrix_completion_SDP_relaxation([[]], "quadratic")           # OMC.jl:1456-1462
+    x = np.zeros(10); x[0] = 1.0
+    with pytest.raises(omc.OmcError) as e:
+        eng.matrix_completion_SDP_relaxation([[(x, np.zeros((10, 1)), ["middle"])]], "linear")   # direction invalid for the type
+    assert e.value.code == -1
+    # contradictory cuts -> INFEASIBLE (OMC.jl:1921-1935: feasible = false)
+    Uh = np.zeros((10, 1)); Uh[0, 0] = 0.5
+    out = eng.matrix_completion_SDP_relaxation([[(x, Uh, ["right"]), (x, -Uh, ["left"])]], "linear", params=omc.default_params(rho_scale=16.0))
+    assert out[0]["termination_status"] == "INFEASIBLE" and not out[0]["feasible"]
+    # a column / row pattern with an empty column is legal input for the relaxation (no observed entries in column 0)
+    mask2 = mask.copy(); mask2[:, 0] = False
+    eng2 = omc.Engine(A, mask2, GAMMA, 1)
+    inst2 = orc.Instance(A, mask2, GAMMA, 1)
+    g = eng2.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=8.0))[0]
+    r = orc.sdp_relaxation(inst2, params=orc.RelaxParams(rho_scale=8.0), want_certificate=False)
+    assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
+    eng.close(); eng2.close()
+
+
+def test_full_size_config2_properties(have_gpu, omc):
+    """BASELINE config 2 shape (100x100, k=1, 20% observed): the oracle would take minutes, so check the
+    size-independent properties: certified gap, bound <= objective, children >= parent, primal feasibility of Y."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(2, seed=0)
+    eng = omc.Engine(A, mask, gamma, c["k"])
+    P = omc.default_params(rho_scale=4.0)
+    root = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P)[0]
+    assert root["status_code"] == 0
+    assert 0 <= root["objective"] - root["dual_bound"] + 1e-6 * root["objective"] <= 2.01e-6 * root["objective"]
+    w = np.linalg.eigvalsh(root["Y"])
+    assert w[0] >= -1e-6 and w[-1] <= 1 + 1e-6 and np.trace(root["Y"]) <= 1 + 1e-9
+    S = np.block([[root["Y"], root["U"]], [root["U"].T, np.eye(1)]])
+    assert np.linalg.eigvalsh(S)[0] >= -1e-6
+    kids = omc.pkg.bnb.make_children([], root, "linear", 1)
+    out = eng.matrix_completion_SDP_relaxation(kids, "linear", params=P, want_X=False)
+    for o in out:
+        assert o["dual_bound"] >= root["dual_bound"] - 2e-6 * abs(root["objective"])
+        assert o["dual_bound"] <= o["objective"] + 1e-6 * abs(o["objective"])
+    ev = eng.evaluate_objective(root["X"])
+    assert ev >= root["objective"] - 1e-6 * abs(ev)      # the relaxation value is below the master objective of its own X
+    eng.close()
