@@ -1030,7 +1030,10 @@ __global__ void k_check_final(OmcWS w, int last) {
   if (fabs(obj - w.objprev[b]) <= 1e-7 * fmax(1.0, fabs(obj)) && lbv <= w.lbprev[b] + 1e-7 * fmax(1.0, fabs(obj))) w.stall[b] += 1;
   else w.stall[b] = 0;
   w.objprev[b] = obj; w.lbprev[b] = w.lb[b];
-  if (w.stall[b] >= w.stall_checks) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }
+  if (w.stall[b] >= w.stall_checks) {
+    const bool okgap = (obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && w.rp[b] <= 10.0 * w.eps_feas * sqrt(Nk);
+    w.done[b] = 1; w.status[b] = okgap ? OMC_ST_OPTIMAL : OMC_ST_SLOW; return;
+  }
   if (last) { w.done[b] = 1; w.status[b] = last; }
 }
 

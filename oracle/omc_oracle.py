@@ -359,6 +359,10 @@ class Instance:
         Lam = np.zeros((self.n, self.m)) if want else None
         for (c, js, idx, a) in self.groups:
             B = np.eye(c)[None] + g * Y[idx[:, :, None], idx[:, None, :]]
+            try:
+                np.linalg.cholesky(B)          # f is +inf outside {I + gamma Y_jj > 0} (the HIP path reports 1e300)
+            except np.linalg.LinAlgError:
+                return (math.inf, Lam) if want else math.inf
             al = np.linalg.solve(B, a[:, :, None])[:, :, 0]
             v += 0.5 * float((a * al).sum())
             if want:
@@ -691,7 +695,9 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
                 stall = 0
             obj_prev = obj; lb_prev = lb
             if stall >= p.stall_checks:
-                break                                                  # SLOW_PROGRESS, values available
+                if (obj - lb) <= p.eps_gap * max(1.0, abs(obj)) and rp <= 10.0 * p.eps_feas * math.sqrt(n + k):
+                    status = OMC_OPTIMAL                               # certified gap, residual within 10x of its target
+                break                                                  # else SLOW_PROGRESS, values available
             if time.time() - t0 > p.time_limit:
                 status = OMC_TIME_LIMIT
                 break

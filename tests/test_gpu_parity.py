@@ -50,8 +50,11 @@ def test_relaxation_matches_oracle(have_gpu, omc, orc, n, m, k, kind, cut_type, 
     eng = omc.Engine(A, mask, GAMMA, k)
     out = eng.matrix_completion_SDP_relaxation(nodes, cut_type, params=omc.default_params(rho_scale=rho_scale), want_Theta=True)
     for g, r in zip(out, ref):
-        assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
         assert g["status_code"] == r["termination_status"]
+        if g["status_code"] == 3:                      # infeasible node: no primal values (OMC.jl:1921-1935)
+            assert not g["feasible"] and g["dual_bound"] > 0.5 * inst.sumA2
+            continue
+        assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
         if g["status_code"] == 0:
             assert g["objective"] - g["dual_bound"] <= 1.01e-6 * max(1.0, abs(g["objective"]))
             assert g["dual_bound"] == pytest.approx(r["dual_bound"], rel=OBJ_REL)
@@ -62,6 +65,8 @@ def test_relaxation_matches_oracle(have_gpu, omc, orc, n, m, k, kind, cut_type, 
         if w[1] - w[0] > 1e-6:
             v = V[:, 0] * np.sign(V[np.argmax(np.abs(V[:, 0])), 0])
             assert np.allclose(g["breakpoint_vec"], v, atol=1e-6)
+        if g["status_code"] != 0:
+            continue                                   # SLOW_PROGRESS: values available but not certified
         # the returned point is feasible for the reference's program (OMC.jl:1554-1685) and reproduces its objective
         Theta = 0.5 * (g["Theta"] + g["Theta"].T)
         res = orc.primal_residuals(inst, r["rows"], g["Y"], g["U"], g["X"], Theta)
