@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <chrono>
@@ -58,7 +59,8 @@ struct omc_instance {
   // batch workspace
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
-  DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin;
+  DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow;
+  int ws_lpp = 0; size_t ws_lds = 0;
   OmcWS ws{};
   omc_relax_params params{};
   bool staged = false;
@@ -161,7 +163,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
-                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin};
+                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -346,7 +348,10 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   ENS(h->balpha, sB * h->nnz * 8); ENS(h->balphaX, sB * h->nnz * 8); ENS(h->bsval, sB * m * 8);
   ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8);
   ENS(h->bG, sB * Rmax * Rmax * 8); ENS(h->blam, sB * Rmax * 8);
-  ENS(h->bscal, sB * 14 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 5 * sizeof(int));
+  ENS(h->bscal, sB * 15 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 6 * sizeof(int));
+  w.np16 = (n + 15) & ~15;
+  ENS(h->bMbuf, sB * w.np16 * w.np16 * 8); ENS(h->bVrow, sB * w.np16 * w.np16 * 8);
+  w.Mbuf = h->bMbuf.as<double>(); w.Vrow = h->bVrow.as<double>();
   w.Y = h->bY.as<double>(); w.Yp = h->bYp.as<double>(); w.U = h->bU.as<double>();
   w.D1 = h->bD1.as<double>(); w.D3 = h->bD3.as<double>(); w.W1 = h->bW1.as<double>(); w.E3 = h->bE3.as<double>();
   w.dS = h->bdS.as<double>();
@@ -361,10 +366,10 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   double* sc = h->bscal.as<double>();
   w.obj = sc; w.objout = sc + sB; w.lb = sc + 2 * sB; w.c0 = sc + 3 * sB; w.evsum = sc + 4 * sB; w.cpen = sc + 5 * sB;
   w.cst = sc + 6 * sB; w.rp = sc + 7 * sB; w.rd = sc + 8 * sB; w.lmin = sc + 9 * sB;  // lmin uses 2B (slots 9,10)
-  w.objprev = sc + 11 * sB; w.lbprev = sc + 12 * sB;
+  w.objprev = sc + 11 * sB; w.lbprev = sc + 12 * sB; w.fro2 = sc + 13 * sB;
   w.bx = h->bbx.as<double>();
   int* ip = h->bint.as<int>();
-  w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB;
+  w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB; w.vvalid = ip + 5 * sB;
   // Q upload
   {
     std::vector<double> hQ(sB * n * rmax, 0.0);
@@ -414,6 +419,14 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     auto cone_bytes = [](int Nn) { int Np = (Nn + 1) & ~1; int ld = Np | 1; return ((size_t)Np * ld + 2 * Np) * 8 + (size_t)Np * 4 + 16; };
     h->cone_lds = cone_bytes(n);
     h->cone_use_lds = h->cone_lds <= OMC_MAX_DYN_LDS;
+    {
+      // warm-started kernel: lanes per pair so that 512 threads cover the n/2 pairs, rows padded to lpp*rpl (<= 20 rows per lane)
+      const int Np2 = (n + 1) & ~1;
+      int lpp = 16; while (lpp > 4 && lpp * (Np2 / 2) > 512) lpp >>= 1;
+      const int rpl = (n + lpp - 1) / lpp, Nrp = rpl * lpp, ldw = Nrp | 1;
+      h->ws_lds = ((size_t)Np2 * ldw + 2 * Np2) * 8 + (size_t)Np2 * 4 + 64;
+      h->ws_lpp = (rpl <= 20 && h->ws_lds <= OMC_MAX_DYN_LDS && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
+    }
     if (!h->cone_use_lds) {
       w.cone_scratch_stride = h->cone_lds / 8 + 8;
       ENS(h->bcone, sB * w.cone_scratch_stride * 8);
@@ -471,7 +484,8 @@ int omc_relax_solve(omc_instance* h) {
   while (it < P.max_iters && nactive > 0) {
     ++it;
     TIMED(OMC_KERNEL_COLPROX, (int64_t)nactive * w.m, omc_launch_colprox(&w, 0, s));
-    TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone(&w, CONE_CLIP01, h->cone_use_lds, h->cone_lds, s));
+    if (h->ws_lpp) TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone_ws(&w, h->ws_lpp, h->ws_lds, s));
+    else TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone(&w, CONE_CLIP01, h->cone_use_lds, h->cone_lds, s));
     TIMED(OMC_KERNEL_SMALL, nactive, omc_launch_small(&w, SMALL_PROJ, h->small_use_lds, h->small_lds, s));
     TIMED(OMC_KERNEL_GLOBAL, nactive, omc_launch_global(&w, h->glob_use_lds, h->glob_lds, s));
     const bool last = (it == P.max_iters);

@@ -25,7 +25,7 @@
 
 struct OmcWS {
   // sizes
-  int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks;
+  int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16;
   // parameters
   double gamma, rho, rho_f, relax, eps_gap, eps_feas, sumA2;
   // instance (device, read-only)
@@ -47,6 +47,9 @@ struct OmcWS {
   double *alpha, *alphaX; // nnz
   double* sval;           // m
   double* Mchk;           // n*n
+  double *Mbuf, *Vrow;    // np16*np16: next cone input Y - D1 (zero padded) ; eigenvectors of the last projection, row-major
+  double* fro2;           // B: ||Mbuf||_F^2
+  int* vvalid;            // B: Vrow holds eigenvectors
   // rows
   int* R;                 // B
   int *rkind, *rcut, *rbi, *rbj;  // B*Rmax
@@ -76,6 +79,7 @@ void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s);
 void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s);
 void omc_launch_global(const OmcWS* w, int use_lds, size_t lds_bytes, hipStream_t s);
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s);
+void omc_launch_cone_ws(const OmcWS* w, int lpp, size_t lds_bytes, hipStream_t s);
 void omc_launch_check_zero(const OmcWS* w, hipStream_t s);
 void omc_launch_check_build(const OmcWS* w, hipStream_t s);
 void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);

@@ -31,7 +31,7 @@ __device__ __forceinline__ double group_sum(double v, int width) {
   return v;
 }
 // block-wide sum, result valid in every thread; red must hold >= 32 doubles
-__device__ double block_sum(double v, double* red) {
+__device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum(v);
   int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
@@ -71,6 +71,15 @@ __global__ void k_setup(OmcWS w) {
     double v = (i == j) ? d0 : 0.0;
     Y[e] = v; Yp[e] = v;
     w.D1[(size_t)b * n * n + e] = 0.0; w.D3[(size_t)b * n * n + e] = 0.0; w.E3[(size_t)b * n * n + e] = 0.0;
+  }
+  {
+    const int NP = w.np16;
+    for (int e = tid; e < NP * NP; e += T) {
+      int i = e % NP, j = e / NP;
+      w.Mbuf[(size_t)b * NP * NP + e] = (i == j && i < n) ? d0 : 0.0;
+      w.Vrow[(size_t)b * NP * NP + e] = 0.0;
+    }
+    if (tid == 0) { w.fro2[b] = d0 * d0 * n; w.vvalid[b] = 0; }
   }
   for (int e = tid; e < n * k; e += T) w.U[(size_t)b * n * k + e] = 0.0;
   for (int e = tid; e < rm * k; e += T) {
@@ -141,7 +150,7 @@ __global__ void k_setup(OmcWS w) {
   } while (0)
 
 // in-place Cholesky of a symmetric matrix stored as packed lower triangle (row r holds q = 0..r)
-__device__ bool wave_cholesky(double* Lm, int c, int lane) {
+__device__ __forceinline__ bool wave_cholesky(double* Lm, int c, int lane) {
   for (int kk = 0; kk < c; ++kk) {
     double piv = Lm[TRI(kk, kk)];
     if (!(piv > 0.0)) return false;
@@ -167,7 +176,7 @@ __device__ bool wave_cholesky(double* Lm, int c, int lane) {
 }
 
 // solve L L' y = rhs (packed L); y, rhs length c
-__device__ void wave_chol_solve(const double* Lm, int c, const double* rhs, double* y, int lane) {
+__device__ __forceinline__ void wave_chol_solve(const double* Lm, int c, const double* rhs, double* y, int lane) {
   for (int r = 0; r < c; ++r) {
     double p = 0.0;
     for (int q = lane; q < r; q += WAVE) p += Lm[TRI(r, q)] * y[q];
@@ -184,27 +193,16 @@ __device__ void wave_chol_solve(const double* Lm, int c, const double* rhs, doub
   }
 }
 
-__global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
-  extern __shared__ double smem[];
-  const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-  const int gw = blockIdx.x * wpb + wave_in_blk;  // global wave id
-  const int b = gw / w.m, j = gw - b * w.m;
-  if (b >= w.B) return;
-  if (w.done[b]) return;
+template <class PT>
+__device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, int j, int off, int c, int lane, PT base) {
   const int n = w.n;
-  const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
-  if (c == 0) return;
   const size_t tri = (size_t)c * (c + 1) / 2;
-  // per-wave storage: Bm, Lm (packed lower triangles), vectors a, y, z, alpha_old
-  double* base;
-  if (c <= w.cp_lds_c) base = smem + (size_t)wave_in_blk * w.cp_lds_doubles;
-  else base = w.cp_scratch + (size_t)gw * w.cp_scratch_stride;
-  double* Bm = base;
-  double* Lm = Bm + tri;
-  double* va = Lm + tri;
-  double* vy = va + c;
-  double* vz = vy + c;
-  double* vo = vz + c;
+  auto Bm = base;
+  auto Lm = Bm + tri;
+  auto va = Lm + tri;
+  auto vy = va + c;
+  auto vz = vy + c;
+  auto vo = vz + c;
   const int* idx = w.col_idx + off;
   const double g = w.gamma;
   const double* Y = w.Y + (size_t)b * n * n;
@@ -291,6 +289,21 @@ __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   }
 }
 
+
+__global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
+  extern __shared__ double smem[];
+  const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int gw = blockIdx.x * wpb + wave_in_blk;  // global wave id
+  const int b = gw / w.m, j = gw - b * w.m;
+  if (b >= w.B) return;
+  if (w.done[b]) return;
+  const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
+  if (c == 0) return;
+  // two inlined copies so that the LDS copy compiles to ds_read/ds_write (not flat) instructions
+  if (c <= w.cp_lds_c) colprox_body(w, mode, b, j, off, c, lane, smem + (size_t)wave_in_blk * w.cp_lds_doubles);
+  else colprox_body(w, mode, b, j, off, c, lane, w.cp_scratch + (size_t)gw * w.cp_scratch_stride);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_cone: symmetric eigendecomposition by one-sided (Hestenes) Jacobi on the SHIFTED matrix M' = M + sigma I,
 // sigma = 1.5 ||M||_F, so that M' is positive definite with condition <= 5.  Columns g_t of G = M' V are then
@@ -312,11 +325,93 @@ __device__ __forceinline__ void rr_pair(int step, int t, int Np, int& p, int& q)
   if (p > q) { int tmp = p; p = q; q = tmp; }
 }
 
-__device__ int jacobi_onesided(double* Gm, int Nr, int Np, int ld, int lpp, double tau, int max_sweeps, int* s_cnt) {
+// ---- cross-lane sums on the VALU (DPP), no LDS traffic: lanes are grouped 4 / 8 / 16 wide inside a row of 16 ----
+__device__ __forceinline__ double dpp_move(double v, const int ctrl_sel) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  int lo2, hi2;
+  switch (ctrl_sel) {
+    case 0: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+  }
+  return __hiloint2double(hi2, lo2);
+}
+template <int LPP>
+__device__ __forceinline__ double group_sum_dpp(double v) {
+  v += dpp_move(v, 0);
+  v += dpp_move(v, 1);
+  if (LPP >= 8) v += dpp_move(v, 2);
+  if (LPP >= 16) v += dpp_move(v, 3);
+  return v;
+}
+
+// One-sided Jacobi with cached squared column norms (only the cross product needs a reduction), DPP reductions,
+// rotations applied from registers, one barrier per step.  nrm2: Np doubles (LDS).  Returns the sweeps done.
+template <int LPP>
+__device__ __forceinline__ int jacobi_sweeps_t(double* Gm, double* nrm2, int Nr, int Np, int ld, double tau, int max_sweeps) {
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int ngroups = T / LPP, grp = tid / LPP, lg = tid % LPP;
+  const int npairs = Np >> 1;
+  const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
+  const double tau2 = tau * tau;
+  int sweeps = 0;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    // refresh the squared norms (analytic updates drift)
+    for (int t = wv; t < Np; t += nw) {
+      double a = 0.0;
+      if (t < Nr) for (int r = lane; r < Nr; r += WAVE) { double x = Gm[(size_t)t * ld + r]; a += x * x; }
+      a = wave_sum(a);
+      if (lane == 0) nrm2[t] = a;
+    }
+    __syncthreads();
+    int rotated = 0;
+    for (int step = 0; step < Np - 1; ++step) {
+      for (int pr = grp; pr < npairs; pr += ngroups) {
+        int p, q;
+        rr_pair(step, pr, Np, p, q);
+        double* gp = Gm + (size_t)p * ld;
+        double* gq = Gm + (size_t)q * ld;
+        double cp_[JROWS], cq_[JROWS];
+        double gm = 0.0;
+#pragma unroll
+        for (int i = 0; i < JROWS; ++i) {
+          const int r = lg + i * LPP;
+          double x = 0.0, y = 0.0;
+          if (r < Nr) { x = gp[r]; y = gq[r]; }
+          cp_[i] = x; cq_[i] = y;
+          gm += x * y;
+        }
+        gm = group_sum_dpp<LPP>(gm);
+        const double a = nrm2[p], bb = nrm2[q];
+        if (gm * gm > tau2 * a * bb && a > 0.0 && bb > 0.0) {
+          // tangent of the rotation angle: only its accuracy relative to 1 matters (c^2 + s^2 = 1 holds by construction)
+          const double zeta = (bb - a) / (2.0 * gm);
+          const double az = fabs(zeta);
+          double tt = 1.0 / (az + sqrt(1.0 + az * az));
+          tt = (zeta >= 0.0) ? tt : -tt;
+          const double cs = rsqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+          for (int i = 0; i < JROWS; ++i) {
+            const int r = lg + i * LPP;
+            if (r < Nr) { gp[r] = cs * cp_[i] - sn * cq_[i]; gq[r] = sn * cp_[i] + cs * cq_[i]; }
+          }
+          if (lg == 0) { nrm2[p] = a - tt * gm; nrm2[q] = bb + tt * gm; }
+          rotated = 1;
+        }
+      }
+      __syncthreads();
+    }
+    if (!__syncthreads_or(rotated)) { ++sweeps; break; }
+  }
+  return sweeps;
+}
+
+// generic fall-back (any N, rows not cached): used when a lane would own more than JROWS rows
+__device__ __forceinline__ int jacobi_onesided(double* Gm, int Nr, int Np, int ld, int lpp, double tau, int max_sweeps, int* s_cnt) {
   const int tid = threadIdx.x, T = blockDim.x;
   const int ngroups = T / lpp, grp = tid / lpp, lg = tid % lpp;
   const int npairs = Np >> 1;
-  const bool cached = (Nr + lpp - 1) / lpp <= JROWS;
   int sweeps = 0;
   for (; sweeps < max_sweeps; ++sweeps) {
     if (tid == 0) *s_cnt = 0;
@@ -328,33 +423,13 @@ __device__ int jacobi_onesided(double* Gm, int Nr, int Np, int ld, int lpp, doub
         double* gp = Gm + (size_t)p * ld;
         double* gq = Gm + (size_t)q * ld;
         double a = 0.0, bb = 0.0, gm = 0.0;
-        double cp_[JROWS], cq_[JROWS];
-        if (cached) {
-#pragma unroll
-          for (int i = 0; i < JROWS; ++i) {
-            int r = lg + i * lpp;
-            double x = 0.0, y = 0.0;
-            if (r < Nr) { x = gp[r]; y = gq[r]; }
-            cp_[i] = x; cq_[i] = y;
-            a += x * x; bb += y * y; gm += x * y;
-          }
-        } else {
-          for (int r = lg; r < Nr; r += lpp) { double x = gp[r], y = gq[r]; a += x * x; bb += y * y; gm += x * y; }
-        }
+        for (int r = lg; r < Nr; r += lpp) { double x = gp[r], y = gq[r]; a += x * x; bb += y * y; gm += x * y; }
         a = group_sum(a, lpp); bb = group_sum(bb, lpp); gm = group_sum(gm, lpp);
         if (fabs(gm) > tau * sqrt(a * bb) && a > 0.0 && bb > 0.0) {
           const double zeta = (bb - a) / (2.0 * gm);
           const double tt = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
           const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-          if (cached) {
-#pragma unroll
-            for (int i = 0; i < JROWS; ++i) {
-              int r = lg + i * lpp;
-              if (r < Nr) { gp[r] = cs * cp_[i] - sn * cq_[i]; gq[r] = sn * cp_[i] + cs * cq_[i]; }
-            }
-          } else {
-            for (int r = lg; r < Nr; r += lpp) { double x = gp[r], y = gq[r]; gp[r] = cs * x - sn * y; gq[r] = sn * x + cs * y; }
-          }
+          for (int r = lg; r < Nr; r += lpp) { double x = gp[r], y = gq[r]; gp[r] = cs * x - sn * y; gq[r] = sn * x + cs * y; }
           if (lg == 0) atomicAdd(s_cnt, 1);
         }
       }
@@ -383,7 +458,7 @@ __device__ __forceinline__ double cone_M_entry(const OmcWS& w, int b, int mode, 
 // Rebuild  out = base*M + sum_{s<nsel} wgt[s] * g_sel[s] g_sel[s]'   in 4x4 register tiles over the lower triangle.
 // `entry(i,j)` returns the original M (only evaluated when base != 0).
 template <class EntryF, class StoreF>
-__device__ void spectral_rebuild(const double* Gm, int ld, int N, const int* sel, const double* wgt, int nsel, double base,
+__device__ __forceinline__ void spectral_rebuild(const double* Gm, int ld, int N, const int* sel, const double* wgt, int nsel, double base,
                                  EntryF entry, StoreF store) {
   const int tid = threadIdx.x, T = blockDim.x;
   const int nt = (N + 3) >> 2;
@@ -425,7 +500,7 @@ __device__ void spectral_rebuild(const double* Gm, int ld, int N, const int* sel
 
 // common front end: load the symmetrised matrix into Gm (Np x ld), shift, Jacobi, squared column norms -> ev
 template <class EntryF>
-__device__ double eig_frontend(double* Gm, double* ev, int N, int Np, int ld, EntryF entry, double* red, int* s_cnt, int* sweeps_out) {
+__device__ __forceinline__ double eig_frontend(double* Gm, double* ev, int N, int Np, int ld, EntryF entry, double* red, int* s_cnt, int* sweeps_out) {
   const int tid = threadIdx.x, T = blockDim.x;
   double fro = 0.0;
   for (int e = tid; e < Np * Np; e += T) {
@@ -440,8 +515,17 @@ __device__ double eig_frontend(double* Gm, double* ev, int N, int Np, int ld, En
   __syncthreads();
   int lpp = 64;
   while (lpp > 1 && lpp * (Np >> 1) > T) lpp >>= 1;
+  if (lpp > 16) lpp = 16;
   const double tau = fmax(1e-14, 2.2e-16 * N);
-  int sweeps = jacobi_onesided(Gm, N, Np, ld, lpp, tau, 30, s_cnt);
+  int sweeps;
+  if (lpp >= 4 && (N + lpp - 1) / lpp <= JROWS) {
+    // ev doubles as the norm cache during the sweeps (recomputed below)
+    if (lpp == 16) sweeps = jacobi_sweeps_t<16>(Gm, ev, N, Np, ld, tau, 30);
+    else if (lpp == 8) sweeps = jacobi_sweeps_t<8>(Gm, ev, N, Np, ld, tau, 30);
+    else sweeps = jacobi_sweeps_t<4>(Gm, ev, N, Np, ld, tau, 30);
+  } else {
+    sweeps = jacobi_onesided(Gm, N, Np, ld, lpp, tau, 30, s_cnt);
+  }
   if (sweeps_out && tid == 0) *sweeps_out += sweeps;
   const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
   for (int t = wv; t < N; t += nw) {
@@ -543,6 +627,164 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
   __syncthreads();
   double* Wout = w.W1 + (size_t)b * n * n;
   auto entry2 = [&](int i, int j) { return 0.5 * (cone_M_entry(w, b, mode, i, j) + cone_M_entry(w, b, mode, j, i)); };
+  auto store = [&](int i, int j, double v, double) { Wout[(size_t)j * n + i] = v; Wout[(size_t)i * n + j] = v; };
+  spectral_rebuild(Gm, ld, N, sel, wgt, s_nsel, s_base, entry2, store);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_cone_ws: the hot kernel.  Spectral clip of M = Y - D1 to [0,1] with a WARM-STARTED one-sided Jacobi:
+//   G = (M + sigma I) V_prev   by v_mfma_f64_16x16x4_f64 (operands straight from L2, result tile -> LDS),
+//   V_prev = eigenvectors of the previous ADMM iteration, so the columns of G are already nearly orthogonal and
+//   one or two sweeps restore orthogonality (quadratic convergence; a sweep whose largest relative cross product
+//   is < 1e-7 is the last one).  Rows are padded to LPP*rpl so the register-cached row loops are wave-uniform.
+// Inputs written by k_global / k_setup: Mbuf (NP16 x NP16, zero padded), fro2, Vrow (row-major V), vvalid.
+// ---------------------------------------------------------------------------------------------------------
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+template <int LPP>
+__global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
+  extern __shared__ double smem[];
+  __shared__ int s_nsel;
+  __shared__ double s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b]) return;
+  const int n = w.n, N = n, NP = w.np16;
+  const int Np = (N + 1) & ~1;
+  const int rpl = (N + LPP - 1) / LPP, Nrp = rpl * LPP, ld = Nrp | 1;
+  double* Gm = smem;
+  double* ev = Gm + (size_t)Np * ld;
+  double* wgt = ev + Np;
+  int* sel = (int*)(wgt + Np);
+  const double* Mb = w.Mbuf + (size_t)b * NP * NP;
+  double* Vr = w.Vrow + (size_t)b * NP * NP;
+  const double sigma = 1.5 * sqrt(w.fro2[b]) + 1e-300;
+  const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
+  // ---- 1. G = (M + sigma I) V_prev  (or M + sigma I on the first call) ------------------------------------
+  for (int e = tid; e < Np * ld; e += T) Gm[e] = 0.0;
+  __syncthreads();
+  if (!w.vvalid[b]) {
+    for (int e = tid; e < N * N; e += T) {
+      int i = e % N, j = e / N;
+      Gm[(size_t)j * ld + i] = Mb[(size_t)j * NP + i] + ((i == j) ? sigma : 0.0);
+    }
+  } else {
+    const int nt = NP >> 4;
+    const int K4 = (N + 3) & ~3;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = wv; tile < nt * nt; tile += nw) {
+      const int ti = tile % nt, tj = tile / nt;
+      const int i0 = ti << 4, j0 = tj << 4;
+      double4v acc = {0.0, 0.0, 0.0, 0.0};
+      const int ia = i0 + li;
+#pragma unroll 4
+      for (int k0 = 0; k0 < K4; k0 += 4) {
+        const int kk = k0 + lk;
+        double a = Mb[(size_t)kk * NP + ia];       // M symmetric: M[ia][kk] = M[kk][ia], contiguous in ia
+        if (ia == kk) a += sigma;
+        const double bv = Vr[(size_t)kk * NP + j0 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+      }
+      const int col = j0 + li;
+      if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + lk + 4 * r;
+          if (row < N) Gm[(size_t)col * ld + row] = acc[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 2. sweeps ---------------------------------------------------------------------------------------------
+  {
+    const int ngroups = T / LPP, grp = tid / LPP, lg = tid % LPP;
+    const int npairs = Np >> 1;
+    const double tau = fmax(1e-14, 2.2e-16 * N), tau2 = tau * tau;
+    int sweeps = 0;
+    for (; sweeps < 30; ++sweeps) {
+      for (int t = wv; t < Np; t += nw) {
+        double a = 0.0;
+        for (int r = lane; r < Nrp; r += WAVE) { double x = Gm[(size_t)t * ld + r]; a += x * x; }
+        a = wave_sum(a);
+        if (lane == 0) ev[t] = a;
+      }
+      __syncthreads();
+      int big = 0;
+      for (int step = 0; step < Np - 1; ++step) {
+        for (int pr = grp; pr < npairs; pr += ngroups) {
+          int p, q;
+          rr_pair(step, pr, Np, p, q);
+          double* gp = Gm + (size_t)p * ld + lg;
+          double* gq = Gm + (size_t)q * ld + lg;
+          double cp_[JROWS], cq_[JROWS];
+          double gm = 0.0;
+#pragma unroll
+          for (int i = 0; i < JROWS; ++i) {
+            if (i < rpl) { cp_[i] = gp[i * LPP]; cq_[i] = gq[i * LPP]; gm += cp_[i] * cq_[i]; }
+          }
+          gm = group_sum_dpp<LPP>(gm);
+          const double a = ev[p], bb = ev[q];
+          const double g2 = gm * gm, ab = a * bb;
+          if (g2 > tau2 * ab && ab > 0.0) {
+            const double d = bb - a;
+            const double rt = sqrt(d * d + 4.0 * g2);
+            const double tt = (2.0 * gm) / ((d >= 0.0) ? (d + rt) : (d - rt));
+            const double cs = rsqrt(1.0 + tt * tt), sn = cs * tt;
+#pragma unroll
+            for (int i = 0; i < JROWS; ++i) {
+              if (i < rpl) { gp[i * LPP] = cs * cp_[i] - sn * cq_[i]; gq[i * LPP] = sn * cp_[i] + cs * cq_[i]; }
+            }
+            if (lg == 0) { ev[p] = a - tt * gm; ev[q] = bb + tt * gm; }
+            if (g2 > 1e-14 * ab) big = 1;
+          }
+        }
+        __syncthreads();
+      }
+      if (!__syncthreads_or(big)) { ++sweeps; break; }   // all cross products were < 1e-7 relative: now < 1e-14
+    }
+    if (tid == 0) w.sweeps[b] += sweeps;
+  }
+  // ---- 3. squared norms, eigenvectors for the next call ---------------------------------------------------------
+  for (int t = wv; t < N; t += nw) {
+    double a = 0.0;
+    for (int r = lane; r < Nrp; r += WAVE) { double x = Gm[(size_t)t * ld + r]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) ev[t] = a;
+  }
+  __syncthreads();
+  for (int e = tid; e < N * N; e += T) {
+    int t = e % N, kk = e / N;     // consecutive threads -> consecutive t -> contiguous row-major store
+    Vr[(size_t)kk * NP + t] = Gm[(size_t)t * ld + kk] * rsqrt(ev[t]);
+  }
+  if (tid == 0) w.vvalid[b] = 1;
+  // ---- 4. clip: rebuild either the defect or the kept part --------------------------------------------------------
+  if (tid == 0) {
+    int ndef = 0, nkeep = 0;
+    for (int t = 0; t < N; ++t) {
+      double lamv = sqrt(ev[t]) - sigma;
+      if (lamv < 0.0 || lamv > 1.0) ++ndef;
+      if (lamv > 0.0) ++nkeep;
+    }
+    int c = 0;
+    if (ndef <= nkeep) {
+      for (int t = 0; t < N; ++t) {
+        double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
+        if (lamv < 0.0) { sel[c] = t; wgt[c] = -lamv / nu2; ++c; }
+        else if (lamv > 1.0) { sel[c] = t; wgt[c] = -(lamv - 1.0) / nu2; ++c; }
+      }
+      s_base = 1.0;
+    } else {
+      for (int t = 0; t < N; ++t) {
+        double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
+        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, 1.0) / nu2; ++c; }
+      }
+      s_base = 0.0;
+    }
+    s_nsel = c;
+  }
+  __syncthreads();
+  double* Wout = w.W1 + (size_t)b * n * n;
+  auto entry2 = [&](int i, int j) { return Mb[(size_t)j * NP + i]; };
   auto store = [&](int i, int j, double v, double) { Wout[(size_t)j * n + i] = v; Wout[(size_t)i * n + j] = v; };
   spectral_rebuild(Gm, ld, N, sel, wgt, s_nsel, s_base, entry2, store);
 }
@@ -693,7 +935,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
 // previous multipliers).  G is R x R (ld = Rmax) in global memory; the passive-set system (<= NNQP_PMAX) is
 // solved by Cholesky in LDS with a tiny ridge (parallel rows make G singular).
 // ---------------------------------------------------------------------------------------------------------
-__device__ void wave_nnqp(const double* G, int ldG, const double* cvec, double* lam, int R, double* Gp, double* sv,
+__device__ __forceinline__ void wave_nnqp(const double* G, int ldG, const double* cvec, double* lam, int R, double* Gp, double* sv,
                           double* tmp, int* plist, int lane) {
   // plist: passive indices (LDS, NNQP_PMAX ints); Gp: PMAX x (PMAX+1); sv,tmp: PMAX doubles
   int np = 0;
@@ -891,7 +1133,9 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     tU[e] = 0.5 * corr;
   }
   __syncthreads();
-  double rp2 = 0.0, rd2 = 0.0;
+  double rp2 = 0.0, rd2 = 0.0, fr2 = 0.0;
+  const int NP = w.np16;
+  double* Mb = w.Mbuf + (size_t)b * NP * NP;
   for (int e = tid; e < r * k; e += T) {
     int a = e % r, j = e / r;
     double qc = 0.0;
@@ -938,13 +1182,19 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     double d3n = (1.0 - rx) * d3 + yold + rx * e3 - yn;
     D1[a1] = d1n; D1[a2] = d1n; D3[a1] = d3n; D3[a2] = d3n;
     double mult = (i == j) ? 1.0 : 2.0;
+    {
+      const double mv = yn - d1n;                      // next input of the cone block
+      Mb[(size_t)j * NP + i] = mv; Mb[(size_t)i * NP + j] = mv;
+      fr2 += mult * mv * mv;
+    }
     rp2 += mult * ((w1 - yn) * (w1 - yn) + (w3y - yn) * (w3y - yn));
     rd2 += mult * (yn - yold) * (yn - yold);
     Yp[a1] = yold; Yp[a2] = yold; Y[a1] = yn; Y[a2] = yn;
   }
   rp2 = block_sum(rp2, red);
   rd2 = block_sum(rd2, red);
-  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.iters[b] += 1; }
+  fr2 = block_sum(fr2, red);
+  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.fro2[b] = fr2; w.iters[b] += 1; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1104,6 +1354,11 @@ void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hi
   if (use_lds) hipLaunchKernelGGL(k_cone<true>, dim3(w->B), dim3(512), lds_bytes, s, *w, mode);
   else hipLaunchKernelGGL(k_cone<false>, dim3(w->B), dim3(512), 0, s, *w, mode);
 }
+void omc_launch_cone_ws(const OmcWS* w, int lpp, size_t lds_bytes, hipStream_t s) {
+  if (lpp == 16) hipLaunchKernelGGL(k_cone_ws<16>, dim3(w->B), dim3(512), lds_bytes, s, *w);
+  else if (lpp == 8) hipLaunchKernelGGL(k_cone_ws<8>, dim3(w->B), dim3(512), lds_bytes, s, *w);
+  else hipLaunchKernelGGL(k_cone_ws<4>, dim3(w->B), dim3(512), lds_bytes, s, *w);
+}
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
   if (use_lds) hipLaunchKernelGGL(k_small<true>, dim3(w->B), dim3(256), lds_bytes, s, *w, mode);
   else hipLaunchKernelGGL(k_small<false>, dim3(w->B), dim3(256), 0, s, *w, mode);
@@ -1130,6 +1385,9 @@ int omc_set_max_lds(void) {
   hipError_t e2 = hipFuncSetAttribute((const void*)k_global<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e3 = hipFuncSetAttribute((const void*)k_colprox, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e4 = hipFuncSetAttribute((const void*)k_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_ws<4>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_ws<16>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   if (e1 != hipSuccess) return 1000 + (int)e1;
   if (e2 != hipSuccess) return 2000 + (int)e2;
   if (e3 != hipSuccess) return 3000 + (int)e3;
