@@ -160,6 +160,32 @@ class Engine:
         _, ev, fe = self.breakpoint_vectors([Y], [U])
         return bool(fe[0])
 
+    # ---- rounding glue + alternating minimisation ---------------------------------------------------------
+    def round_Y(self, Ys):
+        """svd(Y).U[:, 1:k] of the relaxed Y (OMC.jl:873), batched; sign: largest-magnitude entry positive."""
+        B, n, k = len(Ys), self.n, self.k
+        Yb = np.ascontiguousarray(np.stack([np.asfortranarray(y, dtype=np.float64).ravel(order="F") for y in Ys]))
+        U = np.zeros((B, n * k))
+        _lib.check(self._lib.omc_round_Y_batch(self._h, B, _lib.ptr(Yb), _lib.ptr(U)))
+        return [U[b].reshape((n, k), order="F") for b in range(B)]
+
+    def alternating_minimization(self, U_initials, nodes=None, disjunctive_cuts_type="linear", eps=1e-5, max_iters=100,
+                                 time_limit=3600.0, reference_quirk_q1=True):
+        """Batch form of OMC.jl:1979-2279 (use_disjunctive_cuts = true).  Returns dicts with the reference's keys
+        converged, U, V, solve_time, n_iters, max_iters, objectives (OMC.jl:2249-2257)."""
+        n, m, k = self.n, self.m, self.k
+        B = len(U_initials)
+        nodes = nodes if nodes is not None else [[] for _ in range(B)]
+        L, cx, cU, cd = _pack_cuts(nodes, n, k, disjunctive_cuts_type)
+        U0 = np.ascontiguousarray(np.stack([np.asfortranarray(np.asarray(u, float).reshape(n, k)).ravel(order="F") for u in U_initials]))
+        U = np.zeros((B, n * k)); V = np.zeros((B, k * m)); cv = np.zeros(B, np.int32); ni = np.zeros(B, np.int32)
+        obj = np.zeros((B, max_iters)); tm = np.zeros(B)
+        _lib.check(self._lib.omc_altmin_batch(self._h, B, CUT_TYPES[disjunctive_cuts_type], int(reference_quirk_q1), _lib.ptr(L),
+                                              _lib.ptr(cx), _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(U0), float(eps), int(max_iters),
+                                              float(time_limit), _lib.ptr(U), _lib.ptr(V), _lib.ptr(cv), _lib.ptr(ni), _lib.ptr(obj), _lib.ptr(tm)))
+        return [dict(converged=bool(cv[b]), U=U[b].reshape((n, k), order="F"), V=V[b].reshape((k, m), order="F"),
+                     solve_time=float(tm[b]), n_iters=int(ni[b]), max_iters=max_iters, objectives=list(obj[b, :ni[b]])) for b in range(B)]
+
     # ---- objective -------------------------------------------------------------------------------------
     def evaluate_objective(self, X):
         X = np.asarray(X, dtype=np.float64)

@@ -1,0 +1,29 @@
+// omc_altmin.h -- workspace descriptor of the alternating-minimisation kernel
+#ifndef OMC_ALTMIN_H
+#define OMC_ALTMIN_H
+#include <hip/hip_runtime.h>
+struct AltminWS {
+  int B, n, m, Rmax, Lmax, max_iters;
+  double gamma, eps, sumA2;
+  const int *col_ptr, *col_idx; const double* col_val;   // CSC of observed entries
+  const int *row_ptr, *row_idx; const double* row_val;   // CSR of observed entries
+  const int* R;            // B
+  const int *rkind, *rcut, *rbi;   // B*Rmax   (ROW_BOX uses rbi = row index)
+  const double *rcoef, *rrhs;      // B*Rmax   (coefficient on x'u or on u_i)
+  const double* cutx;      // B*Lmax*n
+  const double* U0;        // B*n
+  double *U, *V;           // B*n, B*m
+  double* objectives;      // B*max_iters
+  int *converged, *n_iters;
+  double* G;               // B*Rmax*Rmax scratch
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+void omc_launch_altmin(const void* ws, size_t lds_bytes, hipStream_t s);
+int omc_altmin_set_lds(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

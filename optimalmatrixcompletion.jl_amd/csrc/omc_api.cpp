@@ -20,6 +20,7 @@
 
 #include "omc.h"
 #include "omc_device.h"
+#include "omc_altmin.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -54,6 +55,8 @@ struct omc_instance {
   std::vector<int> col_ptr, col_idx; std::vector<double> col_val;
   std::vector<double> A; std::vector<uint8_t> mask;
   std::vector<double> Ncnt;
+  std::vector<int> row_ptr, row_idx; std::vector<double> row_val;
+  DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG;
   hipStream_t stream = nullptr;
   DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY;
   // batch workspace
@@ -68,6 +71,7 @@ struct omc_instance {
   double last_solve_seconds = 0; long long total_sweeps = 0;
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
+  size_t nnz_rows() const { return row_idx.size(); }
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<int> ev_class;
 };
@@ -131,8 +135,19 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
     for (int p = h->col_ptr[j]; p < h->col_ptr[j + 1]; ++p)
       for (int q = h->col_ptr[j]; q < h->col_ptr[j + 1]; ++q)
         h->Ncnt[(size_t)h->col_idx[q] * n + h->col_idx[p]] += 1.0;
+  // CSR copy (rows -> observed columns) for the U-step of altmin
+  h->row_ptr.assign(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    int c = 0;
+    for (int j = 0; j < m; ++j)
+      if (h->mask[(size_t)j * n + i]) { h->row_idx.push_back(j); h->row_val.push_back(A[(size_t)j * n + i]); ++c; }
+    h->row_ptr[i + 1] = h->row_ptr[i] + c;
+  }
   HIPCHK(hipStreamCreate(&h->stream));
   int rc = 0;
+  if ((rc = upload(h->drow_ptr, h->row_ptr.data(), sizeof(int) * (n + 1), h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->drow_idx, h->row_idx.data(), sizeof(int) * h->nnz_rows(), h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->drow_val, h->row_val.data(), sizeof(double) * h->nnz_rows(), h->stream))) { delete h; return rc; }
   if ((rc = upload(h->dA, h->A.data(), sizeof(double) * n * m, h->stream))) { delete h; return rc; }
   if ((rc = upload(h->dmask, h->mask.data(), (size_t)n * m, h->stream))) { delete h; return rc; }
   if ((rc = upload(h->dcol_ptr, h->col_ptr.data(), sizeof(int) * (m + 1), h->stream))) { delete h; return rc; }
@@ -142,6 +157,7 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   HIPCHK(hipStreamSynchronize(h->stream));
   int lrc = omc_set_max_lds();
   if (lrc) { delete h; return fail(lrc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); }
+  (void)omc_altmin_set_lds();
   omc_relax_params_default(&h->params);
   *out = h;
   return 0;
@@ -163,7 +179,9 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
-                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow};
+                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
+                   &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
+                   &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -608,13 +626,103 @@ int omc_separation_batch(omc_instance* h, int B, int breakpoints, const double* 
   return 0;
 }
 
-int omc_round_Y_batch(omc_instance*, int, const double*, double*) {
-  return fail(OMC_ERR_UNSUPPORTED, "omc_round_Y_batch: not built yet");
+int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded) {
+  if (!h || !Y || !U_rounded) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  std::vector<int> L(B, 0);
+  int rc = omc_relax_stage(h, B, &h->params, OMC_CUT_LINEAR, L.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  const OmcWS& w = h->ws;
+  const size_t n = h->n, k = h->k;
+  HIPCHK(hipMemcpyAsync(w.Y, Y, 8 * (size_t)B * n * n, hipMemcpyHostToDevice, h->stream));
+  omc_launch_cone(&w, CONE_TOPK, h->cone_use_lds, h->cone_lds, h->stream);
+  HIPCHK(hipMemcpyAsync(U_rounded, w.U, 8 * (size_t)B * n * k, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  h->staged = false;
+  return 0;
 }
 
-int omc_altmin_batch(omc_instance*, int, int, int, const int*, const double*, const double*, const int8_t*,
-                     const double*, double, int, double, double*, double*, int*, int*, double*, double*) {
-  return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: not built yet");
+int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q1, const int* L, const double* cut_x,
+                     const double* cut_Uhat, const int8_t* cut_dir, const double* U_initial, double eps, int max_iters,
+                     double time_limit, double* U, double* V, int* converged, int* n_iters, double* objectives,
+                     double* solve_time) {
+  (void)time_limit;
+  if (!h || !U_initial || !U || !V) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (B <= 0 || max_iters <= 0) return fail(OMC_ERR_ARGUMENT, "B and max_iters must be positive");
+  if (cut_type != OMC_CUT_LINEAR && cut_type != OMC_CUT_LINEAR2 && cut_type != OMC_CUT_LINEAR3)
+    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type (OMC.jl:1456-1462)");
+  if (h->k != 1) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: rank k > 1 is not built yet (the oracle covers it)");
+  HIPCHK(hipSetDevice(h->device));
+  const int n = h->n, m = h->m;
+  auto t0 = std::chrono::steady_clock::now();
+  int Lmax = 1; long Ltot = 0;
+  for (int b = 0; b < B; ++b) { int Lb = L ? L[b] : 0; if (Lb < 0) return fail(OMC_ERR_ARGUMENT, "negative cut count"); Lmax = std::max(Lmax, Lb); Ltot += Lb; }
+  if (Ltot > 0 && (!cut_x || !cut_Uhat || !cut_dir)) return fail(OMC_ERR_ARGUMENT, "cut arrays are NULL but L > 0");
+  // rows of model_U: box entries not implied by ||u|| <= 1 (defaults OMC.jl:1989-1996: u_n >= 0), per-cut bounds (2047-2093)
+  const int Rmax = 1 + 2 * Lmax;
+  const size_t sB = (size_t)B;
+  std::vector<int> hR(B, 0), hk(sB * Rmax, 0), hc(sB * Rmax, 0), hbi(sB * Rmax, 0);
+  std::vector<double> hcoef(sB * Rmax, 0.0), hrhs(sB * Rmax, 0.0), hx(sB * Lmax * n, 0.0);
+  long cutbase = 0;
+  for (int b = 0; b < B; ++b) {
+    int r = 0;
+    auto add = [&](int kind, int cut, int bi, double cf, double rhs) {
+      hk[(size_t)b * Rmax + r] = kind; hc[(size_t)b * Rmax + r] = cut; hbi[(size_t)b * Rmax + r] = bi;
+      hcoef[(size_t)b * Rmax + r] = cf; hrhs[(size_t)b * Rmax + r] = rhs; ++r;
+    };
+    add(ROW_BOX, -1, n - 1, -1.0, 0.0);                      // -u_n <= 0  (symmetry breaking, OMC.jl:1991-1993)
+    const int Lb = L ? L[b] : 0;
+    for (int l = 0; l < Lb; ++l) {
+      const double* x = cut_x + (size_t)(cutbase + l) * n;
+      const double* Uh = cut_Uhat + (size_t)(cutbase + l) * n;
+      double vhat = 0.0;
+      for (int i = 0; i < n; ++i) vhat += Uh[i] * x[i];      // OMC.jl:2053
+      double lo, hi, sl, ic;
+      if (cut_piece(cut_type, cut_dir[cutbase + l], vhat, reference_quirk_q1, &lo, &hi, &sl, &ic))
+        return fail(OMC_ERR_INVALID_ENUM, "direction code invalid for this cut type (OMC.jl:2056-2091)");
+      add(ROW_BOUND, l, -1, 1.0, hi);
+      add(ROW_BOUND, l, -1, -1.0, -lo);
+      memcpy(&hx[((size_t)b * Lmax + l) * n], x, sizeof(double) * n);
+    }
+    hR[b] = r; cutbase += Lb;
+  }
+  int rc_ = 0;
+  hipStream_t s = h->stream;
+  if ((rc_ = upload(h->aR, hR.data(), sizeof(int) * B, s))) return rc_;
+  if ((rc_ = upload(h->arkind, hk.data(), sizeof(int) * hk.size(), s))) return rc_;
+  if ((rc_ = upload(h->arcut, hc.data(), sizeof(int) * hc.size(), s))) return rc_;
+  if ((rc_ = upload(h->arbi, hbi.data(), sizeof(int) * hbi.size(), s))) return rc_;
+  if ((rc_ = upload(h->arcoef, hcoef.data(), sizeof(double) * hcoef.size(), s))) return rc_;
+  if ((rc_ = upload(h->arrhs, hrhs.data(), sizeof(double) * hrhs.size(), s))) return rc_;
+  if ((rc_ = upload(h->acutx, hx.data(), sizeof(double) * hx.size(), s))) return rc_;
+  if ((rc_ = upload(h->aU0, U_initial, sizeof(double) * sB * n, s))) return rc_;
+  if ((rc_ = h->aU.ensure(8 * sB * n))) return rc_;
+  if ((rc_ = h->aV.ensure(8 * sB * m))) return rc_;
+  if ((rc_ = h->aobj.ensure(8 * sB * max_iters))) return rc_;
+  if ((rc_ = h->aint.ensure(4 * sB * 2))) return rc_;
+  if ((rc_ = h->aG.ensure(8 * sB * Rmax * Rmax))) return rc_;
+  AltminWS w{};
+  w.B = B; w.n = n; w.m = m; w.Rmax = Rmax; w.Lmax = Lmax; w.max_iters = max_iters;
+  w.gamma = h->gamma; w.eps = eps; w.sumA2 = h->sumA2;
+  w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
+  w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>(); w.row_val = h->drow_val.as<double>();
+  w.R = h->aR.as<int>(); w.rkind = h->arkind.as<int>(); w.rcut = h->arcut.as<int>(); w.rbi = h->arbi.as<int>();
+  w.rcoef = h->arcoef.as<double>(); w.rrhs = h->arrhs.as<double>(); w.cutx = h->acutx.as<double>();
+  w.U0 = h->aU0.as<double>(); w.U = h->aU.as<double>(); w.V = h->aV.as<double>(); w.objectives = h->aobj.as<double>();
+  w.converged = h->aint.as<int>(); w.n_iters = h->aint.as<int>() + B; w.G = h->aG.as<double>();
+  const size_t lds = ((size_t)4 * n + m + 2 * Rmax + 8) * 8;
+  if (lds + 8 * 1024 > OMC_MAX_DYN_LDS) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: n, m too large for the LDS-resident kernel of this round");
+  omc_launch_altmin(&w, lds, s);
+  HIPCHK(hipMemcpyAsync(U, w.U, 8 * sB * n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(V, w.V, 8 * sB * m, hipMemcpyDeviceToHost, s));
+  if (objectives) HIPCHK(hipMemcpyAsync(objectives, w.objectives, 8 * sB * max_iters, hipMemcpyDeviceToHost, s));
+  if (converged) HIPCHK(hipMemcpyAsync(converged, w.converged, 4 * sB, hipMemcpyDeviceToHost, s));
+  if (n_iters) HIPCHK(hipMemcpyAsync(n_iters, w.n_iters, 4 * sB, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (solve_time) for (int b = 0; b < B; ++b) solve_time[b] = el;
+  return 0;
 }
 
 int omc_last_solver_info(omc_instance* h, double* info) {

@@ -12,6 +12,7 @@
 #define CONE_CLIP01 0
 #define CONE_EVALS 2
 #define CONE_SEP 3
+#define CONE_TOPK 4
 #define SMALL_PROJ 0
 #define SMALL_RECOVER 1
 

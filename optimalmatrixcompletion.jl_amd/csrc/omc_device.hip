@@ -16,31 +16,7 @@
 #include <stdint.h>
 #include "omc_device.h"
 
-#define WAVE 64
-
-// ---------------------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
-}
-__device__ __forceinline__ double group_sum(double v, int width) {
-  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
-}
-// block-wide sum, result valid in every thread; red must hold >= 32 doubles
-__device__ __forceinline__ double block_sum(double v, double* red) {
-  v = wave_sum(v);
-  int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
-  __syncthreads();
-  if (l == 0) red[w] = v;
-  __syncthreads();
-  double s = 0.0;
-  for (int i = 0; i < nw; ++i) s += red[i];
-  return s;
-}
+#include "omc_wave.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // k_setup: initial iterate + Gram matrix (for rho = 1) of the linear rows in the metric of the consensus weights
@@ -142,57 +118,6 @@ __global__ void k_setup(OmcWS w) {
 //   mode 1 (exact):  B = I + gamma*Y[O,O], alpha = B^-1 a ;  obj += 1/2 a'alpha ; c0 += a'alpha - 1/2||alpha||^2
 // The c x c matrix lives in LDS (c <= CP_LDS_C) or in a per-wave global scratch slab.
 // ---------------------------------------------------------------------------------------------------------
-#define TRI(r, q) ((size_t)(r) * ((r) + 1) / 2 + (q))
-#define WAVE_SYNC()                                      \
-  do {                                                   \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
-    __builtin_amdgcn_wave_barrier();                     \
-  } while (0)
-
-// in-place Cholesky of a symmetric matrix stored as packed lower triangle (row r holds q = 0..r)
-__device__ __forceinline__ bool wave_cholesky(double* Lm, int c, int lane) {
-  for (int kk = 0; kk < c; ++kk) {
-    double piv = Lm[TRI(kk, kk)];
-    if (!(piv > 0.0)) return false;
-    double d = sqrt(piv);
-    WAVE_SYNC();
-    for (int r = kk + lane; r < c; r += WAVE) {
-      double v = (r == kk) ? d : Lm[TRI(r, kk)] / d;
-      Lm[TRI(r, kk)] = v;
-    }
-    WAVE_SYNC();
-    const int t = c - kk - 1;
-    const int tot = t * t;
-    for (int e = lane; e < tot; e += WAVE) {
-      int rr = e / t, qq = e - rr * t;
-      if (qq <= rr) {
-        int r = kk + 1 + rr, q = kk + 1 + qq;
-        Lm[TRI(r, q)] -= Lm[TRI(r, kk)] * Lm[TRI(q, kk)];
-      }
-    }
-    WAVE_SYNC();
-  }
-  return true;
-}
-
-// solve L L' y = rhs (packed L); y, rhs length c
-__device__ __forceinline__ void wave_chol_solve(const double* Lm, int c, const double* rhs, double* y, int lane) {
-  for (int r = 0; r < c; ++r) {
-    double p = 0.0;
-    for (int q = lane; q < r; q += WAVE) p += Lm[TRI(r, q)] * y[q];
-    p = wave_sum(p);
-    if (lane == 0) y[r] = (rhs[r] - p) / Lm[TRI(r, r)];
-    WAVE_SYNC();
-  }
-  for (int r = c - 1; r >= 0; --r) {
-    double p = 0.0;
-    for (int q = r + 1 + lane; q < c; q += WAVE) p += Lm[TRI(q, r)] * y[q];
-    p = wave_sum(p);
-    if (lane == 0) y[r] = (y[r] - p) / Lm[TRI(r, r)];
-    WAVE_SYNC();
-  }
-}
-
 template <class PT>
 __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, int j, int off, int c, int lane, PT base) {
   const int n = w.n;
@@ -448,6 +373,8 @@ __device__ __forceinline__ double cone_M_entry(const OmcWS& w, int b, int mode, 
     return w.Y[(size_t)b * n * n + (size_t)j * n + i] - w.D1[(size_t)b * n * n + (size_t)j * n + i];
   } else if (mode == CONE_EVALS) {
     return w.Mchk[(size_t)b * n * n + (size_t)j * n + i];
+  } else if (mode == CONE_TOPK) {
+    return w.Y[(size_t)b * n * n + (size_t)j * n + i];
   } else {  // CONE_SEP: U U' - Y
     double s = 0.0;
     for (int t = 0; t < k; ++t) s += w.U[(size_t)b * n * k + (size_t)t * n + i] * w.U[(size_t)b * n * k + (size_t)t * n + j];
@@ -546,7 +473,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
   __shared__ int s_nsel;
   __shared__ double s_base;
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-  if (w.done[b] && mode != CONE_SEP) return;
+  if (w.done[b] && mode != CONE_SEP && mode != CONE_TOPK) return;
   const int n = w.n, k = w.k;
   const int N = n;
   const int Np = (N + 1) & ~1, ld = Np | 1;
@@ -568,6 +495,33 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
       double s = 0.0;
       for (int i = 0; i < kk; ++i) s += fmin(best[i], 0.0);
       w.evsum[b] = s;
+    }
+    return;
+  }
+  if (mode == CONE_TOPK) {
+    // svd(Y).U[:, 1:k] of the symmetric PSD Y (OMC.jl:873): eigenvectors of the k largest eigenvalues, canonical sign
+    __shared__ int s_top[8];
+    __shared__ double s_sg[8];
+    if (tid == 0) {
+      for (int j = 0; j < k; ++j) {
+        int bi = -1; double bl = -1e300;
+        for (int t = 0; t < N; ++t) {
+          bool used = false;
+          for (int q = 0; q < j; ++q) if (s_top[q] == t) used = true;
+          double lamv = sqrt(ev[t]) - sigma;
+          if (!used && lamv > bl) { bl = lamv; bi = t; }
+        }
+        s_top[j] = bi;
+        const double* gt = Gm + (size_t)bi * ld;
+        int a1 = 0;
+        for (int r = 1; r < N; ++r) if (fabs(gt[r]) > fabs(gt[a1])) a1 = r;
+        s_sg[j] = ((gt[a1] >= 0.0) ? 1.0 : -1.0) / sqrt(ev[bi]);
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * k; e += T) {
+      int r = e % N, j = e / N;
+      w.U[(size_t)b * n * k + e] = s_sg[j] * Gm[(size_t)s_top[j] * ld + r];
     }
     return;
   }
@@ -927,111 +881,6 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
     double acc = 0.0;
     for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Q[(size_t)a * n + j];
     E3[(size_t)j * n + i] = acc; E3[(size_t)i * n + j] = acc;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// NNQP on one wave:  min 1/2 l'Gl - c'l, l >= 0  (Lawson-Hanson active set in QP form, warm-started from the
-// previous multipliers).  G is R x R (ld = Rmax) in global memory; the passive-set system (<= NNQP_PMAX) is
-// solved by Cholesky in LDS with a tiny ridge (parallel rows make G singular).
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_nnqp(const double* G, int ldG, const double* cvec, double* lam, int R, double* Gp, double* sv,
-                          double* tmp, int* plist, int lane) {
-  // plist: passive indices (LDS, NNQP_PMAX ints); Gp: PMAX x (PMAX+1); sv,tmp: PMAX doubles
-  int np = 0;
-  // warm start: passive = {lam > 0}
-  for (int r = 0; r < R; ++r) {  // uniform over the wave (lam in LDS/global, same for all lanes)
-    if (lam[r] > 0.0 && np < NNQP_PMAX) { if (lane == 0) plist[np] = r; ++np; }
-    else if (lam[r] != 0.0) { if (lane == 0) lam[r] = 0.0; }
-  }
-  WAVE_SYNC();
-  double cmax = 0.0;
-  for (int r = lane; r < R; r += WAVE) cmax = fmax(cmax, fabs(cvec[r]));
-  for (int o = 32; o > 0; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o, WAVE));
-  const double tol = 1e-13 * fmax(cmax, 1e-300);
-  bool need_inner = (np > 0);
-  for (int outer = 0; outer < 3 * R + 10; ++outer) {
-    if (!need_inner) {
-      // w = c - G lam over non-passive rows; pick the max
-      double best = -1e300; int bi = -1;
-      for (int r = lane; r < R; r += WAVE) {
-        bool inP = false;
-        for (int a = 0; a < np; ++a) if (plist[a] == r) inP = true;
-        if (inP) continue;
-        double wv = cvec[r];
-        for (int a = 0; a < np; ++a) wv -= G[(size_t)r * ldG + plist[a]] * lam[plist[a]];
-        if (wv > best) { best = wv; bi = r; }
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        double ob = __shfl_xor(best, o, WAVE); int oi = __shfl_xor(bi, o, WAVE);
-        if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
-      }
-      if (bi < 0 || best <= tol || np >= NNQP_PMAX) break;
-      if (lane == 0) plist[np] = bi;
-      ++np;
-      WAVE_SYNC();
-    }
-    need_inner = false;
-    // inner loop
-    for (int inner = 0; inner < 3 * NNQP_PMAX + 10; ++inner) {
-      double dmax = 0.0;
-      for (int e = lane; e < np * np; e += WAVE) {
-        int a = e / np, c2 = e - a * np;
-        if (c2 <= a) Gp[TRI(a, c2)] = G[(size_t)plist[a] * ldG + plist[c2]];
-      }
-      for (int a = 0; a < np; ++a) dmax = fmax(dmax, G[(size_t)plist[a] * ldG + plist[a]]);
-      WAVE_SYNC();
-      for (int a = lane; a < np; a += WAVE) { Gp[TRI(a, a)] += 1e-14 * dmax; tmp[a] = cvec[plist[a]]; }
-      WAVE_SYNC();
-      bool ok = wave_cholesky(Gp, np, lane);
-      if (!ok) {  // numerically singular: drop the newest index
-        --np; WAVE_SYNC();
-        if (np == 0) break;
-        continue;
-      }
-      wave_chol_solve(Gp, np, tmp, sv, lane);
-      // all positive?
-      double mins = 1e300;
-      for (int a = lane; a < np; a += WAVE) mins = fmin(mins, sv[a]);
-      for (int o = 32; o > 0; o >>= 1) mins = fmin(mins, __shfl_xor(mins, o, WAVE));
-      if (mins > 0.0) {
-        for (int a = lane; a < np; a += WAVE) lam[plist[a]] = sv[a];
-        WAVE_SYNC();
-        break;
-      }
-      // step toward s until the first multiplier hits zero
-      double al = 1e300;
-      for (int a = lane; a < np; a += WAVE) {
-        double lv = lam[plist[a]];
-        if (sv[a] <= 0.0) al = fmin(al, lv / (lv - sv[a]));
-      }
-      for (int o = 32; o > 0; o >>= 1) al = fmin(al, __shfl_xor(al, o, WAVE));
-      if (!(al >= 0.0)) al = 0.0;
-      for (int a = lane; a < np; a += WAVE) {
-        double lv = lam[plist[a]];
-        lam[plist[a]] = lv + al * (sv[a] - lv);
-      }
-      WAVE_SYNC();
-      // remove zeros (serial compaction, uniform)
-      int nn = 0; bool removed = false; double minl = 1e300; int mini = -1;
-      for (int a = 0; a < np; ++a) {
-        double lv = lam[plist[a]];
-        if (sv[a] <= 0.0 && lv < minl) { minl = lv; mini = a; }
-      }
-      for (int a = 0; a < np; ++a) {
-        int r = plist[a];
-        double lv = lam[r];
-        bool drop = (sv[a] <= 0.0) && (lv <= 1e-18 * fmax(cmax, 1e-300) || a == mini);
-        WAVE_SYNC();
-        if (drop) { if (lane == 0) lam[r] = 0.0; removed = true; }
-        else { if (lane == 0) { plist[nn] = r; } ++nn; }
-        WAVE_SYNC();
-      }
-      // sv must be compacted consistently: recomputed next inner iteration, so nothing to do
-      np = nn;
-      (void)removed;
-      if (np == 0) break;
-    }
   }
 }
 

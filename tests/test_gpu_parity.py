@@ -170,3 +170,33 @@ def test_full_size_config2_properties(have_gpu, omc):
     ev = eng.evaluate_objective(root["X"])
     assert ev >= root["objective"] - 1e-6 * abs(ev)      # the relaxation value is below the master objective of its own X
     eng.close()
+
+
+def test_altmin_and_rounding_match_oracle(have_gpu, omc, orc):
+    """alternating_minimization (OMC.jl:1979-2279) and the SVD rounding glue (OMC.jl:873), rank 1."""
+    n, m, k = 30, 36, 1
+    A, mask = orc.make_instance(n, m, k, seed=31, kind="lowrank", n_indices=int(0.3 * n * m))
+    inst = orc.Instance(A, mask, GAMMA, k)
+    eng = omc.Engine(A, mask, GAMMA, k)
+    U0 = orc.svd_rounding(np.where(mask, A, 0.0), 1)                       # OMC.jl:522-524
+    rng = np.random.default_rng(1)
+    x1 = np.linalg.qr(rng.standard_normal((n, 1)))[0][:, 0]; x2 = np.linalg.qr(rng.standard_normal((n, 1)))[0][:, 0]
+    node_sets = [[], [(x1, U0 * 0.6, ["left"])], [(x1, U0 * 0.6, ["right"]), (x2, -U0 * 0.3, ["left"])]]
+    starts = [U0, U0, U0 + 0.05 * rng.standard_normal((n, 1))]
+    got = eng.alternating_minimization(starts, node_sets, "linear")
+    for g, cuts, u0 in zip(got, node_sets, starts):
+        r = orc.alternating_minimization(inst, u0, cuts, "linear")
+        assert g["converged"] == r["converged"] and g["n_iters"] == r["n_iters"]
+        assert np.allclose(g["objectives"], r["objectives"], rtol=1e-9)
+        assert np.allclose(g["U"], r["U"], atol=1e-7) and np.allclose(g["V"], r["V"], atol=1e-6)
+        assert np.linalg.norm(g["U"]) <= 1 + 1e-9 and g["U"][-1, 0] >= -1e-12
+        X = g["U"] @ g["V"]
+        assert eng.evaluate_objective(X) == pytest.approx(orc.evaluate_objective(X, A, mask, GAMMA), rel=1e-12)
+    # rounding of a relaxed Y
+    out = eng.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=4.0))[0]
+    Ur = eng.round_Y([out["Y"]])[0]
+    ref = orc.svd_rounding(out["Y"], 1)
+    assert np.allclose(Ur, ref, atol=1e-7)
+    with pytest.raises(ValueError):
+        eng.alternating_minimization([U0], [[]], "cubic")
+    eng.close()
