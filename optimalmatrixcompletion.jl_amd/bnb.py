@@ -81,3 +81,200 @@ def allreduce_bounds(upper_bound, lower_bound, group=None):
     t = torch.tensor([float(upper_bound), float(lower_bound)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return float(t[0]), float(t[1])
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Driver counterpart: matrix_completion_branchandbound (OMC.jl:140-1146) with the node evaluation on the GPU.
+# ----------------------------------------------------------------------------------------------------------
+def compute_gap(lower, upper):
+    """OMC.jl:173-179."""
+    return float("inf") if lower < 0 else upper / lower - 1.0
+
+
+def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirst_depthfirst_cutoff=10000, gap=1e-4,
+                     disjunctive_cuts_type="linear", disjunctive_cuts_breakpoints="smallest_1_eigvec", root_only=False,
+                     altmin_flag=True, max_altmin_probability=1.0, min_altmin_probability=0.005,
+                     altmin_probability_decay_rate=1.1, use_max_steps=False, max_steps=1000000, time_limit=3600.0,
+                     batch=64, rho_scale=None, params=None, seed=0, use_certified_bound=True, verbose=False,
+                     rank=0, world_size=1):
+    """Behavioural counterpart of the reference driver for use_disjunctive_cuts = true, no Shor, one altmin run at the
+    root (altmin_root_n_iters = 1).  Differences, all deliberate: (1) up to `batch` nodes are popped per round in the
+    reference's selection order and relaxed in ONE GPU batch (batch=1 reproduces the serial order); (2) the node bound
+    is the certified dual bound (use_certified_bound) instead of the primal value of an eps-optimal point (quirk Q2);
+    (3) the queue is a lazy-deletion heap instead of a rebuild per iteration (OMC.jl:1220-1244), same semantics:
+    key = parent objective, ties by node id; (4) numpy's RNG replaces Julia's for the altmin coin flips (OMC.jl:867).
+    With world_size > 1 every rank runs the same host logic, relaxes its round-robin shard and the results are
+    all-gathered (independent nodes; bounds are reduced implicitly because every rank sees every result).
+    Returns (solution, instance) dicts with the reference's key names where they apply (OMC.jl:604-621, 391-454)."""
+    import heapq
+    import time
+    import math
+    from .api import default_params, BREAKPOINTS
+    if disjunctive_cuts_type not in DIRECTIONS_OF:
+        raise ValueError("Invalid input for disjunctive cuts type.")                       # OMC.jl:217-224
+    if disjunctive_cuts_breakpoints not in BREAKPOINTS:
+        raise ValueError("Invalid input for disjunctive cuts breakpoints.")                # OMC.jl:225-231
+    if node_selection not in ("breadthfirst", "bestfirst", "depthfirst", "bestfirst_depthfirst"):
+        raise ValueError("Invalid input for node selection.")                              # OMC.jl:233-238
+    n, m, k = engine.n, engine.m, engine.k
+    if engine.k != 1 and altmin_flag:
+        raise NotImplementedError("GPU altmin is rank-1 in this round; pass altmin_flag=False for k > 1")
+    rng = np.random.default_rng(seed)                                                      # OMC.jl:333 (Random.seed!(0))
+    start = time.time()
+    counters = dict(nodes_explored=0, nodes_total=1, nodes_dominated=0, nodes_relax_infeasible=0, nodes_relax_feasible=0,
+                    nodes_relax_feasible_pruned=0, nodes_master_feasible=0, nodes_master_feasible_improvement=0,
+                    nodes_relax_feasible_split=0, nodes_relax_feasible_split_altmin=0,
+                    nodes_relax_feasible_split_altmin_improvement=0)
+    run_log = []
+    # ---- root altmin (OMC.jl:521-621) ------------------------------------------------------------------------
+    A0 = np.where(indices, A, 0.0)
+    Uf, _, _ = np.linalg.svd(A0, full_matrices=False)
+    U0 = Uf[:, :k]
+    solution = {}
+    if altmin_flag:
+        am = engine.alternating_minimization([U0], [[]], disjunctive_cuts_type)[0]
+        X0 = am["U"] @ am["V"]
+    else:
+        X0 = U0 @ (U0.T @ A0)
+    Us, _, _ = np.linalg.svd(X0, full_matrices=False)
+    U_init = Us[:, :k]
+    ub = float(engine.evaluate_objective(X0))
+    solution.update(objective_initial=ub, X_initial=X0, U_initial=U_init, Y_initial=U_init @ U_init.T,
+                    objective=ub, X=X0, U=U_init, Y=U_init @ U_init.T, objective_time_found=time.time() - start)
+    if rho_scale is None:
+        rho_scale, _ = autotune_rho_scale(engine, disjunctive_cuts_type)
+    P = params or default_params(rho_scale=float(rho_scale), breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints])
+    # ---- tree ------------------------------------------------------------------------------------------------
+    nodes = {1: dict(cuts=[], LB=-math.inf, depth=0, parent=0)}
+    heap = [(math.inf, 1)]            # (key = parent objective, node id)   OMC.jl:697
+    fifo = [1]
+    lb = -math.inf
+    now_gap = math.inf
+    t_relax = t_altmin = 0.0
+    altmin_decay_depth = math.log(max_altmin_probability / min_altmin_probability, altmin_probability_decay_rate) if altmin_flag else 0.0
+
+    def pop_ids(cnt):
+        out = []
+        sel = node_selection
+        if sel == "bestfirst_depthfirst":
+            sel = "depthfirst" if len(nodes) > bestfirst_depthfirst_cutoff else "bestfirst"      # OMC.jl:709-717
+        while len(out) < cnt and nodes:
+            if sel == "bestfirst":
+                while heap and heap[0][1] not in nodes:
+                    heapq.heappop(heap)
+                if not heap:
+                    break
+                _, nid = heapq.heappop(heap)
+            elif sel == "breadthfirst":
+                while fifo and fifo[0] not in nodes:
+                    fifo.pop(0)
+                if not fifo:
+                    break
+                nid = fifo.pop(0)
+            else:
+                while fifo and fifo[-1] not in nodes:
+                    fifo.pop()
+                if not fifo:
+                    break
+                nid = fifo.pop()
+            if nid in nodes:
+                out.append(nid)
+        return out
+
+    while now_gap > gap and not (use_max_steps and counters["nodes_total"] >= max_steps) and time.time() - start <= time_limit and nodes:
+        ids = pop_ids(batch)
+        if not ids:
+            break
+        popped = [(nid, nodes.pop(nid)) for nid in ids]
+        counters["nodes_explored"] += len(popped)
+        todo = []
+        for nid, nd in popped:
+            if nd["LB"] > ub:                                                               # OMC.jl:725-728
+                counters["nodes_dominated"] += 1
+            else:
+                todo.append((nid, nd))
+        if todo:
+            t0 = time.time()
+            mine = todo[rank::world_size] if world_size > 1 else todo
+            res_mine = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in mine], disjunctive_cuts_type, params=P,
+                                                               want_X=True) if mine else []
+            if world_size > 1:
+                import torch.distributed as dist
+                gathered = [None] * world_size
+                dist.all_gather_object(gathered, [(nid, r) for (nid, _), r in zip(mine, res_mine)])
+                bynid = {nid: r for part in gathered for nid, r in part}
+                results = [bynid[nid] for nid, _ in todo]
+            else:
+                results = res_mine
+            t_relax += time.time() - t0
+            split = []
+            for (nid, nd), r in zip(todo, results):
+                if not r["feasible"]:                                                        # OMC.jl:777-779
+                    counters["nodes_relax_infeasible"] += 1
+                    continue
+                counters["nodes_relax_feasible"] += 1                                       # OMC.jl:786
+                bound = r["dual_bound"] if use_certified_bound else r["objective"]
+                nd["LB"] = bound
+                if nid == 1:
+                    lb = bound                                                              # OMC.jl:793-795
+                if bound > ub:                                                               # OMC.jl:797-800
+                    counters["nodes_relax_feasible_pruned"] += 1
+                    continue
+                if r["status_code"] == 0 and r["lambda_min"][0] >= -1e-6:                    # OMC.jl:807-837
+                    counters["nodes_master_feasible"] += 1
+                    if r["objective"] < ub:
+                        counters["nodes_master_feasible_improvement"] += 1
+                        ub = r["objective"]
+                        solution.update(objective=ub, X=r["X"], U=r["U"], Y=r["Y"], objective_time_found=time.time() - start)
+                    continue
+                split.append((nid, nd, r))
+            # altmin at split nodes w.p. p(depth)  (OMC.jl:856-949)
+            if altmin_flag and split:
+                chosen = []
+                for nid, nd, r in split:
+                    p = min_altmin_probability if nd["depth"] > altmin_decay_depth else max_altmin_probability / (altmin_probability_decay_rate ** nd["depth"])
+                    if rng.random() < p:
+                        chosen.append((nid, nd, r))
+                if chosen:
+                    t0 = time.time()
+                    Ur = engine.round_Y([r["Y"] for _, _, r in chosen])                      # OMC.jl:873
+                    ams = engine.alternating_minimization(Ur, [nd["cuts"] for _, nd, _ in chosen], disjunctive_cuts_type)
+                    counters["nodes_relax_feasible_split_altmin"] += len(chosen)
+                    conv = [(a["U"] @ a["V"]) for a in ams if a["converged"]]               # OMC.jl:919-920
+                    if conv:
+                        objs = engine.evaluate_objective(np.stack(conv))                     # OMC.jl:925-927
+                        j = int(np.argmin(objs))
+                        for o in objs:
+                            if o < ub:
+                                counters["nodes_relax_feasible_split_altmin_improvement"] += 1
+                        if objs[j] < ub:
+                            ub = float(objs[j]); Xl = conv[j]
+                            Ul = np.linalg.svd(Xl, full_matrices=False)[0][:, :k]            # OMC.jl:921
+                            solution.update(objective=ub, X=Xl, U=Ul, Y=Ul @ Ul.T, objective_time_found=time.time() - start)
+                    t_altmin += time.time() - t0
+            for nid, nd, r in split:                                                         # OMC.jl:951-989
+                counters["nodes_relax_feasible_split"] += 1
+                kids = make_children(nd["cuts"], r, disjunctive_cuts_type, k)
+                for cuts in kids:
+                    counters["nodes_total"] += 1
+                    cid = counters["nodes_total"]
+                    nodes[cid] = dict(cuts=cuts, LB=nd["LB"], depth=nd["depth"] + 1, parent=nid)
+                    heapq.heappush(heap, (nd["LB"], cid)); fifo.append(cid)
+        # prune dominated nodes (OMC.jl:1220-1244) and update the global lower bound (OMC.jl:1207-1218)
+        for nid in [i for i, nd in nodes.items() if nd["LB"] > ub]:
+            del nodes[nid]
+        if nodes:
+            minval = min(nd["LB"] for nd in nodes.values())
+            if minval > lb:
+                lb = minval
+        now_gap = compute_gap(lb, ub)
+        run_log.append((counters["nodes_explored"], counters["nodes_total"], len(nodes), lb, ub, now_gap, time.time() - start))
+        if verbose:
+            print("| %10d | %10d | %10d | %10f | %10f | %10f | %10.3f  s  |" % run_log[-1], flush=True)
+        if root_only:
+            break
+    elapsed = time.time() - start
+    solution.update(lower_bound=lb, gap=now_gap)
+    instance = dict(run_log=run_log, run_details=dict(counters, time_taken=elapsed, solve_time_relaxation=t_relax, solve_time_altmin=t_altmin,
+                                                      rho_scale=float(rho_scale), batch=batch, n=n, m=m, k=k))
+    return solution, instance

@@ -73,19 +73,18 @@ __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
     auto solve = [&](double theta) -> double {
       for (int i = tid; i < n; i += T) u0[i] = g[i] / (h[i] + theta);
       __syncthreads();
-      for (int e = 0; e < R * R; ++e) {
+      // one thread per Gram entry / per row (R is small: serial dot products of length n beat R^2 block reductions)
+      for (int e = tid; e < R * R; e += T) {
         int r1 = e / R, r2 = e - r1 * R;
         if (r2 < r1) continue;
         double acc = 0.0;
-        for (int i = tid; i < n; i += T) { double a1 = am_row_entry(w, b, r1, i); if (a1 != 0.0) acc += a1 * am_row_entry(w, b, r2, i) / (h[i] + theta); }
-        double tot = block_sum(acc, red);
-        if (tid == 0) { G[(size_t)r1 * w.Rmax + r2] = tot; G[(size_t)r2 * w.Rmax + r1] = tot; }
+        for (int i = 0; i < n; ++i) { double a1 = am_row_entry(w, b, r1, i); if (a1 != 0.0) acc += a1 * am_row_entry(w, b, r2, i) / (h[i] + theta); }
+        G[(size_t)r1 * w.Rmax + r2] = acc; G[(size_t)r2 * w.Rmax + r1] = acc;
       }
-      for (int r = 0; r < R; ++r) {
+      for (int r = tid; r < R; r += T) {
         double acc = 0.0;
-        for (int i = tid; i < n; i += T) acc += am_row_entry(w, b, r, i) * u0[i];
-        double tot = block_sum(acc, red);
-        if (tid == 0) cvec[r] = tot - w.rrhs[(size_t)b * w.Rmax + r];
+        for (int i = 0; i < n; ++i) acc += am_row_entry(w, b, r, i) * u0[i];
+        cvec[r] = acc - w.rrhs[(size_t)b * w.Rmax + r];
       }
       __syncthreads();
       if (R > 0 && tid < 64) wave_nnqp(G, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid);
