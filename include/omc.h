@@ -118,6 +118,9 @@ int omc_relax_batch(omc_instance* h, int B, const omc_relax_params* params, int 
 int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
                     const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
                     const double* U_upper);
+/* Optional: per-node penalty scales for the NEXT omc_relax_stage / omc_relax_batch with the same B (consumed by it).
+ * Lets one batch try several penalties on the root (autotune) or give children their parent's value. */
+int omc_set_node_rho_scales(omc_instance* h, int B, const double* rho_scale);
 int omc_relax_solve(omc_instance* h);
 int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int* status, int* iters, double* Y,
                     double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x,

@@ -84,8 +84,13 @@ class Engine:
             pass
 
     # ---- relaxation ------------------------------------------------------------------------------------
-    def stage(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None):
+    def stage(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None, rho_scales=None):
         n, k = self.n, self.k
+        if rho_scales is not None:
+            rs = np.ascontiguousarray(np.asarray(rho_scales, dtype=np.float64))
+            if rs.shape != (len(nodes),):
+                raise ValueError("rho_scales must hold one value per node")
+            _lib.check(self._lib.omc_set_node_rho_scales(self._h, len(nodes), _lib.ptr(rs)))
         L, cx, cU, cd = _pack_cuts(nodes, n, k, disjunctive_cuts_type)
         p = params or default_params()
         B = len(nodes)
@@ -126,9 +131,9 @@ class Engine:
         return out
 
     def matrix_completion_SDP_relaxation(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None,
-                                         want_Y=True, want_X=True, want_Theta=False):
+                                         want_Y=True, want_X=True, want_Theta=False, rho_scales=None):
         """Batch form of OMC.jl:1431-1943 (use_disjunctive_cuts = true, no Shor).  `nodes` = list of cut lists."""
-        self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper)
+        self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper, rho_scales)
         self.solve()
         return self.fetch(want_Y, want_X, want_Theta)
 

@@ -32,17 +32,18 @@ def make_children(cuts, relax_result, cut_type, k):
     return [list(cuts) + [(x, U, d)] for d in child_directions(cut_type, k)]
 
 
-def autotune_rho_scale(engine, cut_type="linear", scales=(0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0), max_iters=3000, **params):
-    """Solve the root once per candidate and keep the penalty scale that certifies the gap in the fewest iterations."""
+def autotune_rho_scale(engine, cut_type="linear", scales=(0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0), max_iters=600, **params):
+    """Relax the root once per candidate penalty -- all candidates in ONE GPU batch (per-node penalties) -- and keep the
+    scale that certifies the gap in the fewest iterations.  Returns (scale, log, root_result_of_the_winner)."""
     from .api import default_params
-    best = None; log = []
-    for sc in scales:
-        p = default_params(rho_scale=float(sc), max_iters=max_iters, **params)
-        out = engine.matrix_completion_SDP_relaxation([[]], cut_type, params=p, want_Y=False, want_X=False)[0]
-        log.append((float(sc), out["status_code"], out["iters"]))
-        if out["status_code"] == 0 and (best is None or out["iters"] < best[1]):
-            best = (float(sc), out["iters"])
-    return (best[0] if best else 1.0), log
+    p = default_params(rho_scale=1.0, max_iters=max_iters, **params)
+    outs = engine.matrix_completion_SDP_relaxation([[] for _ in scales], cut_type, params=p, rho_scales=list(scales))
+    log = [(float(sc), o["status_code"], o["iters"]) for sc, o in zip(scales, outs)]
+    ok = [(o["iters"], i) for i, o in enumerate(outs) if o["status_code"] == 0]
+    if not ok:
+        return 1.0, log
+    _, i = min(ok)
+    return float(scales[i]), log
 
 
 def expand_frontier(engine, depth, cut_type="linear", params=None, max_nodes=None):

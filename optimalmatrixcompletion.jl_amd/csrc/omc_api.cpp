@@ -63,12 +63,13 @@ struct omc_instance {
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
   DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow;
-  int ws_lpp = 0; size_t ws_lds = 0;
+  int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
   OmcWS ws{};
   omc_relax_params params{};
   bool staged = false;
   int cone_use_lds = 0, glob_use_lds = 0, small_use_lds = 0; size_t cone_lds = 0, glob_lds = 0, small_lds = 0;
   double last_solve_seconds = 0; long long total_sweeps = 0;
+  std::vector<double> rho_scale_per_node; DevBuf brho;
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
   size_t nnz_rows() const { return row_idx.size(); }
@@ -180,7 +181,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
-                   &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
+                   &h->brho, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -349,7 +350,15 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.rho = P.rho_scale * 0.5 * h->gamma * h->sumA2 / ((double)m * sh * sh);
   }
   if (!(w.rho > 0.0)) w.rho = 1.0;
-  w.rho_f = w.rho * P.rho_f_ratio;
+  w.rho_f_ratio = P.rho_f_ratio;
+  {
+    std::vector<double> hr(B, w.rho);
+    if (h->rho_scale_per_node.size() == (size_t)B)
+      for (int b = 0; b < B; ++b) hr[b] = w.rho / P.rho_scale * h->rho_scale_per_node[b];
+    h->rho_scale_per_node.clear();
+    int r0 = upload(h->brho, hr.data(), sizeof(double) * B, h->stream); if (r0) return r0;
+    w.rho_b = h->brho.as<double>();
+  }
   w.relax = P.relax; w.eps_gap = P.eps_gap; w.eps_feas = P.eps_feas;
   std::vector<double> wY((size_t)n * n);
   for (size_t e = 0; e < (size_t)n * n; ++e) wY[e] = P.rho_f_ratio * h->Ncnt[e] + 2.0;
@@ -438,17 +447,23 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     h->cone_lds = cone_bytes(n);
     h->cone_use_lds = h->cone_lds <= OMC_MAX_DYN_LDS;
     {
-      // warm-started kernel: lanes per pair so that 512 threads cover the n/2 pairs, rows padded to lpp*rpl (<= 20 rows per lane)
+      // warm-started kernel: lanes per pair so that 512 threads cover the n/2 pairs, rows padded to lpp*rpl (<= 20 rows per lane).
+      // G lives in LDS when it fits, else in the per-node global scratch (L2 resident) with 16 lanes per pair.
       const int Np2 = (n + 1) & ~1;
       int lpp = 16; while (lpp > 4 && lpp * (Np2 / 2) > 512) lpp >>= 1;
-      const int rpl = (n + lpp - 1) / lpp, Nrp = rpl * lpp, ldw = Nrp | 1;
+      int rpl = (n + lpp - 1) / lpp, Nrp = rpl * lpp, ldw = Nrp | 1;
       h->ws_lds = ((size_t)Np2 * ldw + 2 * Np2) * 8 + (size_t)Np2 * 4 + 64;
-      h->ws_lpp = (rpl <= 20 && h->ws_lds <= OMC_MAX_DYN_LDS && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
-    }
-    if (!h->cone_use_lds) {
-      w.cone_scratch_stride = h->cone_lds / 8 + 8;
-      ENS(h->bcone, sB * w.cone_scratch_stride * 8);
-      w.cone_scratch = h->bcone.as<double>();
+      h->ws_use_lds = h->ws_lds <= OMC_MAX_DYN_LDS;
+      if (!h->ws_use_lds) {
+        lpp = 16; rpl = (n + 15) / 16; Nrp = rpl * 16; ldw = Nrp | 1;
+        const size_t need = ((size_t)Np2 * ldw + 2 * Np2) * 8 + (size_t)Np2 * 4 + 64;
+        if (need / 8 + 8 > w.cone_scratch_stride) {
+          w.cone_scratch_stride = need / 8 + 8;
+          ENS(h->bcone, sB * w.cone_scratch_stride * 8);
+          w.cone_scratch = h->bcone.as<double>();
+        }
+      }
+      h->ws_lpp = (rpl <= 20 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
     }
     h->glob_lds = ((size_t)n * n + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8;
     h->glob_use_lds = h->glob_lds + 12 * 1024 <= OMC_MAX_DYN_LDS;
@@ -483,6 +498,13 @@ static int finish_events(omc_instance* h) {
   return 0;
 }
 
+int omc_set_node_rho_scales(omc_instance* h, int B, const double* rho_scale) {
+  if (!h || B <= 0 || !rho_scale) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  for (int b = 0; b < B; ++b) if (!(rho_scale[b] > 0.0)) return fail(OMC_ERR_ARGUMENT, "rho_scale must be positive");
+  h->rho_scale_per_node.assign(rho_scale, rho_scale + B);
+  return 0;
+}
+
 int omc_relax_solve(omc_instance* h) {
   if (!h || !h->staged) return fail(OMC_ERR_ARGUMENT, "omc_relax_solve: nothing staged");
   HIPCHK(hipSetDevice(h->device));
@@ -502,7 +524,7 @@ int omc_relax_solve(omc_instance* h) {
   while (it < P.max_iters && nactive > 0) {
     ++it;
     TIMED(OMC_KERNEL_COLPROX, (int64_t)nactive * w.m, omc_launch_colprox(&w, 0, s));
-    if (h->ws_lpp) TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone_ws(&w, h->ws_lpp, h->ws_lds, s));
+    if (h->ws_lpp) TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone_ws(&w, h->ws_lpp, h->ws_use_lds, h->ws_lds, s));
     else TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone(&w, CONE_CLIP01, h->cone_use_lds, h->cone_lds, s));
     TIMED(OMC_KERNEL_SMALL, nactive, omc_launch_small(&w, SMALL_PROJ, h->small_use_lds, h->small_lds, s));
     TIMED(OMC_KERNEL_GLOBAL, nactive, omc_launch_global(&w, h->glob_use_lds, h->glob_lds, s));

@@ -28,7 +28,8 @@ struct OmcWS {
   // sizes
   int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16;
   // parameters
-  double gamma, rho, rho_f, relax, eps_gap, eps_feas, sumA2;
+  double gamma, rho, rho_f_ratio, relax, eps_gap, eps_feas, sumA2;   // rho: batch default (rho_b holds the per-node value)
+  const double* rho_b;    // B: ADMM penalty of node b
   // instance (device, read-only)
   const int* col_ptr;     // m+1
   const int* col_idx;     // nnz: observed rows of each column, ascending
@@ -80,7 +81,7 @@ void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s);
 void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s);
 void omc_launch_global(const OmcWS* w, int use_lds, size_t lds_bytes, hipStream_t s);
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s);
-void omc_launch_cone_ws(const OmcWS* w, int lpp, size_t lds_bytes, hipStream_t s);
+void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, hipStream_t s);
 void omc_launch_check_zero(const OmcWS* w, hipStream_t s);
 void omc_launch_check_build(const OmcWS* w, hipStream_t s);
 void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);

@@ -138,7 +138,8 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
     vo[p] = (mode == 0) ? alpha[p] : 0.0;
   }
   WAVE_SYNC();
-  const double coef = (mode == 0) ? g / (2.0 * w.rho_f) : 0.0;
+  const double rho_f = w.rho_b[b] * w.rho_f_ratio;
+  const double coef = (mode == 0) ? g / (2.0 * rho_f) : 0.0;
   for (int e = lane; e < c * c; e += WAVE) {
     int p = e / c, q = e - p * c;
     if (q > p) continue;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
   WAVE_SYNC();
   double s = 0.0;
   if (mode == 0) {
-    const double cp = g * g / (2.0 * w.rho_f);
+    const double cp = g * g / (2.0 * rho_f);
     double sprev = w.sval[(size_t)b * w.m + j];
     s = (sprev > 0.0) ? sprev : 0.0;
     double lo = 0.0, hi = -1.0;  // hi < 0: unknown
@@ -595,7 +596,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
 // ---------------------------------------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
 
-template <int LPP>
+template <int LPP, bool USE_LDS>
 __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   extern __shared__ double smem[];
   __shared__ int s_nsel;
@@ -605,9 +606,9 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   const int n = w.n, N = n, NP = w.np16;
   const int Np = (N + 1) & ~1;
   const int rpl = (N + LPP - 1) / LPP, Nrp = rpl * LPP, ld = Nrp | 1;
-  double* Gm = smem;
-  double* ev = Gm + (size_t)Np * ld;
-  double* wgt = ev + Np;
+  auto Gm = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.cone_scratch + (size_t)b * w.cone_scratch_stride; }();
+  auto ev = Gm + (size_t)Np * ld;
+  auto wgt = ev + Np;
   int* sel = (int*)(wgt + Np);
   const double* Mb = w.Mbuf + (size_t)b * NP * NP;
   double* Vr = w.Vrow + (size_t)b * NP * NP;
@@ -668,8 +669,8 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
         for (int pr = grp; pr < npairs; pr += ngroups) {
           int p, q;
           rr_pair(step, pr, Np, p, q);
-          double* gp = Gm + (size_t)p * ld + lg;
-          double* gq = Gm + (size_t)q * ld + lg;
+          auto gp = Gm + (size_t)p * ld + lg;
+          auto gq = Gm + (size_t)q * ld + lg;
           double cp_[JROWS], cq_[JROWS];
           double gm = 0.0;
 #pragma unroll
@@ -919,7 +920,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const double* E3 = w.E3 + (size_t)b * n * n;
   const double* W3V = w.W3V + (size_t)b * rm * k;
   const double* Q = w.Qb + (size_t)b * n * rm;
-  const double rho = w.rho, rho_f = w.rho_f, rx = w.relax, g = w.gamma;
+  const double rho = w.rho_b[b], rho_f = rho * w.rho_f_ratio, rx = w.relax, g = w.gamma;
   // 1. cone + multiplicity part of the target
   for (int e = tid; e < n * n; e += T) {
     double y = Y[e];
@@ -1064,7 +1065,7 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
   const double* lam = w.lam + (size_t)b * w.Rmax;
   const double* cutx = w.cutx + (size_t)b * w.Lmax * n;
   const double* Q = w.Qb + (size_t)b * n * rm;
-  const double rho = w.rho, g = w.gamma;
+  const double rho = w.rho_b[b], g = w.gamma;
   double* cU = w.chk_scratch + (size_t)b * n * k;
   for (int e = tid; e < n * n; e += T) {
     int i = e % n, j = e / n;
@@ -1203,10 +1204,14 @@ void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hi
   if (use_lds) hipLaunchKernelGGL(k_cone<true>, dim3(w->B), dim3(512), lds_bytes, s, *w, mode);
   else hipLaunchKernelGGL(k_cone<false>, dim3(w->B), dim3(512), 0, s, *w, mode);
 }
-void omc_launch_cone_ws(const OmcWS* w, int lpp, size_t lds_bytes, hipStream_t s) {
-  if (lpp == 16) hipLaunchKernelGGL(k_cone_ws<16>, dim3(w->B), dim3(512), lds_bytes, s, *w);
-  else if (lpp == 8) hipLaunchKernelGGL(k_cone_ws<8>, dim3(w->B), dim3(512), lds_bytes, s, *w);
-  else hipLaunchKernelGGL(k_cone_ws<4>, dim3(w->B), dim3(512), lds_bytes, s, *w);
+void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, hipStream_t s) {
+  if (use_lds) {
+    if (lpp == 16) hipLaunchKernelGGL((k_cone_ws<16, true>), dim3(w->B), dim3(512), lds_bytes, s, *w);
+    else if (lpp == 8) hipLaunchKernelGGL((k_cone_ws<8, true>), dim3(w->B), dim3(512), lds_bytes, s, *w);
+    else hipLaunchKernelGGL((k_cone_ws<4, true>), dim3(w->B), dim3(512), lds_bytes, s, *w);
+  } else {
+    hipLaunchKernelGGL((k_cone_ws<16, false>), dim3(w->B), dim3(512), 0, s, *w);
+  }
 }
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
   if (use_lds) hipLaunchKernelGGL(k_small<true>, dim3(w->B), dim3(256), lds_bytes, s, *w, mode);
@@ -1234,9 +1239,9 @@ int omc_set_max_lds(void) {
   hipError_t e2 = hipFuncSetAttribute((const void*)k_global<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e3 = hipFuncSetAttribute((const void*)k_colprox, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e4 = hipFuncSetAttribute((const void*)k_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  (void)hipFuncSetAttribute((const void*)k_cone_ws<4>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  (void)hipFuncSetAttribute((const void*)k_cone_ws<8>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  (void)hipFuncSetAttribute((const void*)k_cone_ws<16>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_ws<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_ws<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_ws<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   if (e1 != hipSuccess) return 1000 + (int)e1;
   if (e2 != hipSuccess) return 2000 + (int)e2;
   if (e3 != hipSuccess) return 3000 + (int)e3;
