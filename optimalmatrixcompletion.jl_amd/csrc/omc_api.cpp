@@ -343,6 +343,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   OmcWS& w = h->ws;
   memset(&w, 0, sizeof(w));
   w.B = B; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
+  w.jacobi_tau = getenv("OMC_JACOBI_TAU") ? atof(getenv("OMC_JACOBI_TAU")) : 0.0;
+  w.max_sweeps = getenv("OMC_DEBUG_MAX_SWEEPS") ? atoi(getenv("OMC_DEBUG_MAX_SWEEPS")) : 30;
   w.breakpoints = P.breakpoints; w.stall_checks = P.stall_checks > 0 ? P.stall_checks : 1000000;
   w.gamma = h->gamma; w.sumA2 = h->sumA2;
   {
@@ -451,11 +453,11 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       // G lives in LDS when it fits, else in the per-node global scratch (L2 resident) with 16 lanes per pair.
       const int Np2 = (n + 1) & ~1;
       int lpp = 16; while (lpp > 4 && lpp * (Np2 / 2) > 512) lpp >>= 1;
-      int rpl = (n + lpp - 1) / lpp, Nrp = rpl * lpp, ldw = Nrp | 1;
+      int rpl = (((n + lpp - 1) / lpp) + 1) & ~1, Nrp = rpl * lpp, ldw = Nrp + 2;
       h->ws_lds = ((size_t)Np2 * ldw + 2 * Np2) * 8 + (size_t)Np2 * 4 + 64;
       h->ws_use_lds = h->ws_lds <= OMC_MAX_DYN_LDS;
       if (!h->ws_use_lds) {
-        lpp = 16; rpl = (n + 15) / 16; Nrp = rpl * 16; ldw = Nrp | 1;
+        lpp = 16; rpl = (((n + 15) / 16) + 1) & ~1; Nrp = rpl * 16; ldw = Nrp + 2;
         const size_t need = ((size_t)Np2 * ldw + 2 * Np2) * 8 + (size_t)Np2 * 4 + 64;
         if (need / 8 + 8 > w.cone_scratch_stride) {
           w.cone_scratch_stride = need / 8 + 8;

@@ -26,9 +26,9 @@
 
 struct OmcWS {
   // sizes
-  int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16;
+  int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16, max_sweeps;
   // parameters
-  double gamma, rho, rho_f_ratio, relax, eps_gap, eps_feas, sumA2;   // rho: batch default (rho_b holds the per-node value)
+  double gamma, rho, rho_f_ratio, relax, eps_gap, eps_feas, sumA2, jacobi_tau;   // rho: batch default (rho_b holds the per-node value)
   const double* rho_b;    // B: ADMM penalty of node b
   // instance (device, read-only)
   const int* col_ptr;     // m+1

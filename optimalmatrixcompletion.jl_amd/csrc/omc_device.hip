@@ -151,12 +151,28 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
   }
   WAVE_SYNC();
   double s = 0.0;
+  const bool regpath = (c <= WAVE);        // vectors in registers (lane r owns entry r)
+  auto dinv = vz;                          // reuse: reciprocals of the Cholesky diagonal
+  const double a_reg = (lane < c) ? va[lane] : 0.0;
+  auto solve2 = [&](double& y_out, double& z_out, bool want_z) {
+    if (regpath) {
+      for (int p = lane; p < c; p += WAVE) dinv[p] = 1.0 / Lm[TRI(p, p)];
+      WAVE_SYNC();
+      y_out = wave_chol_solve_reg(Lm, dinv, c, a_reg, lane);
+      z_out = want_z ? wave_chol_solve_reg(Lm, dinv, c, y_out, lane) : 0.0;
+    } else {
+      wave_chol_solve(Lm, c, va, vy, lane);
+      if (want_z) wave_chol_solve(Lm, c, vy, vz, lane);
+    }
+  };
   if (mode == 0) {
     const double cp = g * g / (2.0 * rho_f);
     double sprev = w.sval[(size_t)b * w.m + j];
     s = (sprev > 0.0) ? sprev : 0.0;
     double lo = 0.0, hi = -1.0;  // hi < 0: unknown
     bool lo_valid = false;       // lo_valid: Cholesky succeeded at lo and phi(lo) >= 0
+    double yr = 0.0, zr = 0.0;
+    bool have_final = false;
     for (int it = 0; it < 60; ++it) {
       for (int e = lane; e < c * c; e += WAVE) {
         int p = e / c, q = e - p * c;
@@ -169,10 +185,10 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
         s = (hi > 0.0) ? 0.5 * (s + hi) : (2.0 * s + 1.0);
         continue;
       }
-      wave_chol_solve(Lm, c, va, vy, lane);
-      wave_chol_solve(Lm, c, vy, vz, lane);
+      solve2(yr, zr, true);
       double yy = 0.0, yz = 0.0;
-      for (int p = lane; p < c; p += WAVE) { yy += vy[p] * vy[p]; yz += vy[p] * vz[p]; }
+      if (regpath) { yy = yr * yr; yz = yr * zr; }
+      else for (int p = lane; p < c; p += WAVE) { yy += vy[p] * vy[p]; yz += vy[p] * vz[p]; }
       yy = wave_sum(yy); yz = wave_sum(yz);
       const double ph = yy - s, dph = -2.0 * cp * yz - 1.0;
       if (ph >= 0.0) { lo = s; lo_valid = true; } else { hi = s; }
@@ -180,19 +196,22 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
       if (!(sn > lo) && !lo_valid) sn = 0.5 * (lo + s);
       if (sn < lo) sn = lo;
       if (hi > 0.0 && sn > hi) sn = 0.5 * (lo + hi);
-      if (fabs(sn - s) <= 4e-16 * fmax(1.0, fabs(s))) { s = sn; break; }
+      // alpha(s) is Lipschitz in s with constant << 1 here: once the Newton step is below 1e-13 |s| the current solve IS the answer
+      if (fabs(sn - s) <= 1e-13 * fmax(1.0, fabs(s))) { have_final = true; break; }
       s = sn;
     }
-    // final solve at the converged s (vy currently holds the solve at the previous s: redo once, cheap)
-    for (int e = lane; e < c * c; e += WAVE) {
-      int p = e / c, q = e - p * c;
-      if (q <= p) Lm[TRI(p, q)] = Bm[TRI(p, q)] + ((p == q) ? cp * s : 0.0);
+    if (!have_final) {
+      for (int e = lane; e < c * c; e += WAVE) {
+        int p = e / c, q = e - p * c;
+        if (q <= p) Lm[TRI(p, q)] = Bm[TRI(p, q)] + ((p == q) ? cp * s : 0.0);
+      }
+      WAVE_SYNC();
+      wave_cholesky(Lm, c, lane);
+      solve2(yr, zr, false);
     }
-    WAVE_SYNC();
-    wave_cholesky(Lm, c, lane);
-    wave_chol_solve(Lm, c, va, vy, lane);
     if (lane == 0) w.sval[(size_t)b * w.m + j] = s;
-    for (int p = lane; p < c; p += WAVE) alpha[p] = vy[p];
+    if (regpath) { if (lane < c) alpha[lane] = yr; }
+    else for (int p = lane; p < c; p += WAVE) alpha[p] = vy[p];
   } else {
     for (int e = lane; e < c * c; e += WAVE) {
       int p = e / c, q = e - p * c;
@@ -204,9 +223,11 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
       if (lane == 0) atomicAdd(&w.obj[b], 1e300);
       return;
     }
-    wave_chol_solve(Lm, c, va, vy, lane);
+    double yr = 0.0, zr = 0.0;
+    solve2(yr, zr, false);
     double aa = 0.0, al2 = 0.0;
-    for (int p = lane; p < c; p += WAVE) { aa += va[p] * vy[p]; al2 += vy[p] * vy[p]; alpha[p] = vy[p]; }
+    if (regpath) { aa = a_reg * yr; al2 = yr * yr; if (lane < c) alpha[lane] = yr; }
+    else for (int p = lane; p < c; p += WAVE) { aa += va[p] * vy[p]; al2 += vy[p] * vy[p]; alpha[p] = vy[p]; }
     aa = wave_sum(aa); al2 = wave_sum(al2);
     if (lane == 0) {
       atomicAdd(&w.obj[b], 0.5 * aa);
@@ -214,7 +235,6 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
     }
   }
 }
-
 
 __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   extern __shared__ double smem[];
@@ -247,29 +267,11 @@ __device__ __forceinline__ void rr_pair(int step, int t, int Np, int& p, int& q)
   // round-robin tournament on Np (even) players: step in [0,Np-1), t in [0,Np/2)
   const int M1 = Np - 1;
   if (t == 0) { p = step; q = Np - 1; }
-  else { p = (step + t) % M1; q = (step - t + M1) % M1; }
-  if (p > q) { int tmp = p; p = q; q = tmp; }
-}
-
-// ---- cross-lane sums on the VALU (DPP), no LDS traffic: lanes are grouped 4 / 8 / 16 wide inside a row of 16 ----
-__device__ __forceinline__ double dpp_move(double v, const int ctrl_sel) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  int lo2, hi2;
-  switch (ctrl_sel) {
-    case 0: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
-    case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
-    case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
-    default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+  else {
+    p = step + t; if (p >= M1) p -= M1;          // step < M1, t < M1: one conditional subtraction replaces the modulo
+    q = step - t; if (q < 0) q += M1;
   }
-  return __hiloint2double(hi2, lo2);
-}
-template <int LPP>
-__device__ __forceinline__ double group_sum_dpp(double v) {
-  v += dpp_move(v, 0);
-  v += dpp_move(v, 1);
-  if (LPP >= 8) v += dpp_move(v, 2);
-  if (LPP >= 16) v += dpp_move(v, 3);
-  return v;
+  if (p > q) { int tmp = p; p = q; q = tmp; }
 }
 
 // One-sided Jacobi with cached squared column norms (only the cross product needs a reduction), DPP reductions,
@@ -596,7 +598,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
 // ---------------------------------------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
 
-template <int LPP, bool USE_LDS>
+template <int LPP, bool USE_LDS, int RPL2>   // RPL2 = rows per lane / 2 as a compile-time constant (0: run-time bound)
 __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   extern __shared__ double smem[];
   __shared__ int s_nsel;
@@ -605,7 +607,8 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   if (w.done[b]) return;
   const int n = w.n, N = n, NP = w.np16;
   const int Np = (N + 1) & ~1;
-  const int rpl = (N + LPP - 1) / LPP, Nrp = rpl * LPP, ld = Nrp | 1;
+  // lane lg of a pair group owns the CONTIGUOUS rows [lg*rpl, (lg+1)*rpl): 16-byte LDS reads, rpl even, ld even
+  const int rpl = (((N + LPP - 1) / LPP) + 1) & ~1, Nrp = rpl * LPP, ld = Nrp + 2;
   auto Gm = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.cone_scratch + (size_t)b * w.cone_scratch_stride; }();
   auto ev = Gm + (size_t)Np * ld;
   auto wgt = ev + Np;
@@ -631,12 +634,16 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
       const int i0 = ti << 4, j0 = tj << 4;
       double4v acc = {0.0, 0.0, 0.0, 0.0};
       const int ia = i0 + li;
-#pragma unroll 4
+      // software pipeline: operands of step k0+4 are in flight while the MFMA of step k0 issues
+      double a_n = Mb[(size_t)lk * NP + ia] + ((ia == lk) ? sigma : 0.0);
+      double b_n = Vr[(size_t)lk * NP + j0 + li];
       for (int k0 = 0; k0 < K4; k0 += 4) {
-        const int kk = k0 + lk;
-        double a = Mb[(size_t)kk * NP + ia];       // M symmetric: M[ia][kk] = M[kk][ia], contiguous in ia
-        if (ia == kk) a += sigma;
-        const double bv = Vr[(size_t)kk * NP + j0 + li];
+        const double a = a_n, bv = b_n;
+        const int kn = k0 + 4 + lk;
+        if (k0 + 4 < K4) {
+          a_n = Mb[(size_t)kn * NP + ia] + ((ia == kn) ? sigma : 0.0);
+          b_n = Vr[(size_t)kn * NP + j0 + li];
+        }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
       }
       const int col = j0 + li;
@@ -654,9 +661,11 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   {
     const int ngroups = T / LPP, grp = tid / LPP, lg = tid % LPP;
     const int npairs = Np >> 1;
-    const double tau = fmax(1e-14, 2.2e-16 * N), tau2 = tau * tau;
+    // rotation threshold 1e-10 (relative cross product): the projection error it leaves, ~1e-10 ||M||, is far below the
+    // ADMM tolerances; 1e-14 would force a second rotating sweep that changes nothing the solver can see
+    const double tau = (w.jacobi_tau > 0.0) ? w.jacobi_tau : 1e-10, tau2 = tau * tau;
     int sweeps = 0;
-    for (; sweeps < 30; ++sweeps) {
+    for (; sweeps < w.max_sweeps; ++sweeps) {
       for (int t = wv; t < Np; t += nw) {
         double a = 0.0;
         for (int r = lane; r < Nrp; r += WAVE) { double x = Gm[(size_t)t * ld + r]; a += x * x; }
@@ -669,28 +678,39 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
         for (int pr = grp; pr < npairs; pr += ngroups) {
           int p, q;
           rr_pair(step, pr, Np, p, q);
-          auto gp = Gm + (size_t)p * ld + lg;
-          auto gq = Gm + (size_t)q * ld + lg;
-          double cp_[JROWS], cq_[JROWS];
-          double gm = 0.0;
+          typedef double double2v __attribute__((ext_vector_type(2)));
+          auto gp = (double2v*)(Gm + (size_t)p * ld + lg * rpl);
+          auto gq = (double2v*)(Gm + (size_t)q * ld + lg * rpl);
+          const int rpl2 = rpl >> 1;
+          constexpr int R2 = RPL2 ? RPL2 : JROWS / 2;
+          double2v cp_[R2], cq_[R2];
+          double gm0 = 0.0, gm1 = 0.0;
 #pragma unroll
-          for (int i = 0; i < JROWS; ++i) {
-            if (i < rpl) { cp_[i] = gp[i * LPP]; cq_[i] = gq[i * LPP]; gm += cp_[i] * cq_[i]; }
+          for (int i = 0; i < R2; ++i) {
+            if (RPL2 || i < rpl2) { cp_[i] = gp[i]; cq_[i] = gq[i]; gm0 += cp_[i].x * cq_[i].x; gm1 += cp_[i].y * cq_[i].y; }
           }
-          gm = group_sum_dpp<LPP>(gm);
+          double gm = group_sum_dpp<LPP>(gm0 + gm1);
           const double a = ev[p], bb = ev[q];
           const double g2 = gm * gm, ab = a * bb;
           if (g2 > tau2 * ab && ab > 0.0) {
-            const double d = bb - a;
-            const double rt = sqrt(d * d + 4.0 * g2);
-            const double tt = (2.0 * gm) / ((d >= 0.0) ? (d + rt) : (d - rt));
+            // tangent in fp32 (its error only slows the last digits of convergence: the next visit of the pair sees a
+            // cross product reduced by ~1e-7 instead of 1e-16), cosine/sine in fp64 so the rotation stays orthogonal
+            const float df = (float)(bb - a), gf = (float)gm;
+            const float rtf = __builtin_sqrtf(df * df + 4.0f * gf * gf);
+            const float den = (df >= 0.0f) ? (df + rtf) : (df - rtf);
+            const double tt = (den != 0.0f) ? (double)((2.0f * gf) / den) : 0.0;
             const double cs = rsqrt(1.0 + tt * tt), sn = cs * tt;
 #pragma unroll
-            for (int i = 0; i < JROWS; ++i) {
-              if (i < rpl) { gp[i * LPP] = cs * cp_[i] - sn * cq_[i]; gq[i * LPP] = sn * cp_[i] + cs * cq_[i]; }
+            for (int i = 0; i < R2; ++i) {
+              if (RPL2 || i < rpl2) {
+                double2v np_, nq_;
+                np_.x = cs * cp_[i].x - sn * cq_[i].x; np_.y = cs * cp_[i].y - sn * cq_[i].y;
+                nq_.x = sn * cp_[i].x + cs * cq_[i].x; nq_.y = sn * cp_[i].y + cs * cq_[i].y;
+                gp[i] = np_; gq[i] = nq_;
+              }
             }
             if (lg == 0) { ev[p] = a - tt * gm; ev[q] = bb + tt * gm; }
-            if (g2 > 1e-14 * ab) big = 1;
+            if (g2 > tau * ab) big = 1;   // relative cross product above sqrt(tau): one more sweep needed
           }
         }
         __syncthreads();
@@ -1192,6 +1212,17 @@ __global__ void __launch_bounds__(256) k_eval_objective(int n, int m, double gam
 // ---------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------
+template <int LPP>
+static void launch_ws_lds(const OmcWS* w, int rpl2, size_t lds_bytes, hipStream_t s) {
+  switch (rpl2) {   // straight-line (branch-free) row loops for the common sizes, run-time bound otherwise
+    case 4: hipLaunchKernelGGL((k_cone_ws<LPP, true, 4>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
+    case 5: hipLaunchKernelGGL((k_cone_ws<LPP, true, 5>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
+    case 6: hipLaunchKernelGGL((k_cone_ws<LPP, true, 6>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
+    case 7: hipLaunchKernelGGL((k_cone_ws<LPP, true, 7>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
+    case 8: hipLaunchKernelGGL((k_cone_ws<LPP, true, 8>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
+    default: hipLaunchKernelGGL((k_cone_ws<LPP, true, 0>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
+  }
+}
 extern "C" {
 void omc_launch_setup(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s) {
@@ -1205,12 +1236,13 @@ void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hi
   else hipLaunchKernelGGL(k_cone<false>, dim3(w->B), dim3(512), 0, s, *w, mode);
 }
 void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, hipStream_t s) {
+  const int rpl2 = ((((w->n + lpp - 1) / lpp) + 1) & ~1) >> 1;
   if (use_lds) {
-    if (lpp == 16) hipLaunchKernelGGL((k_cone_ws<16, true>), dim3(w->B), dim3(512), lds_bytes, s, *w);
-    else if (lpp == 8) hipLaunchKernelGGL((k_cone_ws<8, true>), dim3(w->B), dim3(512), lds_bytes, s, *w);
-    else hipLaunchKernelGGL((k_cone_ws<4, true>), dim3(w->B), dim3(512), lds_bytes, s, *w);
+    if (lpp == 16) launch_ws_lds<16>(w, rpl2, lds_bytes, s);
+    else if (lpp == 8) launch_ws_lds<8>(w, rpl2, lds_bytes, s);
+    else launch_ws_lds<4>(w, rpl2, lds_bytes, s);
   } else {
-    hipLaunchKernelGGL((k_cone_ws<16, false>), dim3(w->B), dim3(512), 0, s, *w);
+    hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->B), dim3(512), 0, s, *w);
   }
 }
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
@@ -1239,9 +1271,9 @@ int omc_set_max_lds(void) {
   hipError_t e2 = hipFuncSetAttribute((const void*)k_global<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e3 = hipFuncSetAttribute((const void*)k_colprox, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e4 = hipFuncSetAttribute((const void*)k_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  (void)hipFuncSetAttribute((const void*)k_cone_ws<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  (void)hipFuncSetAttribute((const void*)k_cone_ws<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  (void)hipFuncSetAttribute((const void*)k_cone_ws<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+#define WS_ATTR(L, R) (void)hipFuncSetAttribute((const void*)k_cone_ws<L, true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS)
+#define WS_ATTR_ALL(L) WS_ATTR(L, 0); WS_ATTR(L, 4); WS_ATTR(L, 5); WS_ATTR(L, 6); WS_ATTR(L, 7); WS_ATTR(L, 8)
+  WS_ATTR_ALL(4); WS_ATTR_ALL(8); WS_ATTR_ALL(16);
   if (e1 != hipSuccess) return 1000 + (int)e1;
   if (e2 != hipSuccess) return 2000 + (int)e2;
   if (e3 != hipSuccess) return 3000 + (int)e3;

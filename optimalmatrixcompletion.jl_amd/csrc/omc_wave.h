@@ -9,10 +9,34 @@
 // ---------------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+// ---- cross-lane sums on the VALU (DPP), no LDS traffic: lanes are grouped 4 / 8 / 16 wide inside a row of 16 ----
+__device__ __forceinline__ double dpp_move(double v, const int ctrl_sel) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  int lo2, hi2;
+  switch (ctrl_sel) {
+    case 0: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+  }
+  return __hiloint2double(hi2, lo2);
+}
+template <int LPP>
+__device__ __forceinline__ double group_sum_dpp(double v) {
+  v += dpp_move(v, 0);
+  v += dpp_move(v, 1);
+  if (LPP >= 8) v += dpp_move(v, 2);
+  if (LPP >= 16) v += dpp_move(v, 3);
   return v;
+}
+
+__device__ __forceinline__ double readlane_d(double v, int l) {   // l must be wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// full-wave sum without LDS traffic: DPP inside each row of 16 lanes, then four scalar reads
+__device__ __forceinline__ double wave_sum(double v) {
+  v = group_sum_dpp<16>(v);
+  return readlane_d(v, 0) + readlane_d(v, 16) + readlane_d(v, 32) + readlane_d(v, 48);
 }
 __device__ __forceinline__ double group_sum(double v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -61,6 +85,24 @@ __device__ __forceinline__ bool wave_cholesky(double* Lm, int c, int lane) {
     WAVE_SYNC();
   }
   return true;
+}
+
+// solve L L' y = rhs with the vector held in registers (lane r owns entry r, c <= 64): column-oriented substitution,
+// one scalar broadcast (v_readlane) per step instead of a cross-lane reduction per row.  dinv[q] = 1 / L[q][q].
+template <class LP, class DP>
+__device__ __forceinline__ double wave_chol_solve_reg(LP Lm, DP dinv, int c, double rhs, int lane) {
+  double y = (lane < c) ? rhs : 0.0;
+  for (int q = 0; q < c; ++q) {
+    const double zq = readlane_d(y, q) * dinv[q];
+    if (lane == q) y = zq;
+    else if (lane > q && lane < c) y -= Lm[TRI(lane, q)] * zq;
+  }
+  for (int q = c - 1; q >= 0; --q) {
+    const double xq = readlane_d(y, q) * dinv[q];
+    if (lane == q) y = xq;
+    else if (lane < q) y -= Lm[TRI(q, lane)] * xq;
+  }
+  return y;
 }
 
 // solve L L' y = rhs (packed L); y, rhs length c
