@@ -155,6 +155,8 @@ int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded
 #define OMC_KERNEL_NCLASS 6
 /* info[8]: solve seconds, total Jacobi sweeps of k_cone, rho, r_max, LDS flags (cone, global, small), R_max */
 int omc_last_solver_info(omc_instance* h, double* info);
+/* diagnostic builds (-DOMC_STAMPS) only: accumulated s_memtime ticks per kernel phase of node 0; zeros otherwise */
+int omc_debug_stamps(omc_instance* h, double* out32);
 int omc_last_kernel_stats(omc_instance* h, int64_t* launches /*NCLASS*/, double* ms /*NCLASS*/,
                           int64_t* units /*NCLASS*/);
 

@@ -69,7 +69,7 @@ struct omc_instance {
   bool staged = false;
   int cone_use_lds = 0, glob_use_lds = 0, small_use_lds = 0; size_t cone_lds = 0, glob_lds = 0, small_lds = 0;
   double last_solve_seconds = 0; long long total_sweeps = 0;
-  std::vector<double> rho_scale_per_node; DevBuf brho;
+  std::vector<double> rho_scale_per_node; DevBuf brho, blamD;
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
   size_t nnz_rows() const { return row_idx.size(); }
@@ -181,7 +181,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
-                   &h->brho, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
+                   &h->brho, &h->blamD, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -368,6 +368,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   if ((rc_ = upload(h->dwY, wY.data(), sizeof(double) * n * n, h->stream))) return rc_;
   w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
   w.Ncnt = h->dNcnt.as<double>(); w.wY1 = h->dwY.as<double>();
+  w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>();
 #define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)
   const size_t sB = (size_t)B;
   ENS(h->bY, sB * n * n * 8); ENS(h->bYp, sB * n * n * 8); ENS(h->bU, sB * n * k * 8);
@@ -375,11 +376,14 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   ENS(h->bdS, sB * rmax * rmax * 8);
   ENS(h->bsm, sB * ((size_t)4 * rmax * k + 3 * k * k) * 8);
   ENS(h->balpha, sB * h->nnz * 8); ENS(h->balphaX, sB * h->nnz * 8); ENS(h->bsval, sB * m * 8);
-  ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8);
+  ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8 + 32 * 8);
   ENS(h->bG, sB * Rmax * Rmax * 8); ENS(h->blam, sB * Rmax * 8);
   ENS(h->bscal, sB * 15 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 6 * sizeof(int));
   w.np16 = (n + 15) & ~15;
   ENS(h->bMbuf, sB * w.np16 * w.np16 * 8); ENS(h->bVrow, sB * w.np16 * w.np16 * 8);
+  ENS(h->blamD, sB * m * n * 8);
+  HIPCHK(hipMemsetAsync(h->blamD.p, 0, sB * m * n * 8, h->stream));
+  w.lamD = h->blamD.as<double>();
   w.Mbuf = h->bMbuf.as<double>(); w.Vrow = h->bVrow.as<double>();
   w.Y = h->bY.as<double>(); w.Yp = h->bYp.as<double>(); w.U = h->bU.as<double>();
   w.D1 = h->bD1.as<double>(); w.D3 = h->bD3.as<double>(); w.W1 = h->bW1.as<double>(); w.E3 = h->bE3.as<double>();
@@ -391,7 +395,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.D3T = sm + 4 * vk; w.W3T = sm + 4 * vk + tk; w.Q3T = sm + 4 * vk + 2 * tk;
   }
   w.alpha = h->balpha.as<double>(); w.alphaX = h->balphaX.as<double>(); w.sval = h->bsval.as<double>();
-  w.Mchk = h->bMchk.as<double>(); w.chk_scratch = h->bchk.as<double>(); w.G = h->bG.as<double>(); w.lam = h->blam.as<double>();
+  w.Mchk = h->bMchk.as<double>(); w.chk_scratch = h->bchk.as<double>(); w.stamps = h->bchk.as<double>() + sB * n * k; w.G = h->bG.as<double>(); w.lam = h->blam.as<double>();
   double* sc = h->bscal.as<double>();
   w.obj = sc; w.objout = sc + sB; w.lb = sc + 2 * sB; w.c0 = sc + 3 * sB; w.evsum = sc + 4 * sB; w.cpen = sc + 5 * sB;
   w.cst = sc + 6 * sB; w.rp = sc + 7 * sB; w.rd = sc + 8 * sB; w.lmin = sc + 9 * sB;  // lmin uses 2B (slots 9,10)
@@ -467,7 +471,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       }
       h->ws_lpp = (rpl <= 20 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
     }
-    h->glob_lds = ((size_t)n * n + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8;
+    h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8 + (size_t)h->nnz * 4 + 16;   // n*m >= n*n: the region also stages Lambda
     h->glob_use_lds = h->glob_lds + 12 * 1024 <= OMC_MAX_DYN_LDS;
     if (!h->glob_use_lds) {
       w.glob_scratch_stride = h->glob_lds / 8 + 8;
@@ -486,6 +490,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     }
   }
   HIPCHK(hipMemsetAsync(w.sweeps, 0, sizeof(int) * B, h->stream));
+  HIPCHK(hipMemsetAsync(w.stamps, 0, 32 * 8, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->staged = true;
   return 0;
@@ -746,6 +751,12 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   HIPCHK(hipGetLastError());
   const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (solve_time) for (int b = 0; b < B; ++b) solve_time[b] = el;
+  return 0;
+}
+
+int omc_debug_stamps(omc_instance* h, double* out32) {
+  if (!h || !out32 || !h->ws.stamps) return fail(OMC_ERR_ARGUMENT, "no stamps");
+  HIPCHK(hipMemcpy(out32, h->ws.stamps, 32 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 

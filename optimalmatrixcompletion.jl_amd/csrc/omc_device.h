@@ -35,6 +35,9 @@ struct OmcWS {
   const int* col_idx;     // nnz: observed rows of each column, ascending
   const double* col_val;  // nnz: A at those
   const double* Ncnt;     // n*n: number of columns observing both rows
+  const int* row_ptr;     // n+1: CSR of the observed entries (row -> observed columns)
+  const int* row_idx;     // nnz
+  double* lamD;           // B*m*n: dense column-major copy of Lambda (zero off the support)
   const double* wY1;      // n*n: consensus weight of Y entries for rho = 1: rho_f_ratio*Ncnt + 2
   // per-node state (node stride in comments)
   double *Y, *Yp;         // n*n
@@ -71,6 +74,7 @@ struct OmcWS {
   double* glob_scratch; size_t glob_scratch_stride;
   double* small_scratch; size_t small_scratch_stride;
   double* chk_scratch;   // B*n*k
+  double* stamps;        // 32 doubles (diagnostic builds)
 };
 
 #ifdef __cplusplus

@@ -18,6 +18,15 @@
 
 #include "omc_wave.h"
 
+// optional phase stamps (diagnostic builds only: -DOMC_STAMPS): block 0 accumulates s_memtime deltas per phase
+#ifdef OMC_STAMPS
+#define STAMP(slot) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { long long t_ = __builtin_amdgcn_s_memtime(); w.stamps[slot] += (double)(t_ - t_prev_); t_prev_ = t_; } } while (0)
+#define STAMP_BEGIN() long long t_prev_ = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(slot) do {} while (0)
+#define STAMP_BEGIN() do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // k_setup: initial iterate + Gram matrix (for rho = 1) of the linear rows in the metric of the consensus weights
 //   rows of node b:  <CY_r, Y> + <CU_r, U> <= rhs_r ;  CY_r = I (trace) | x x' (cut) | 0 ;  CU_r = x (x) coef_r
@@ -210,8 +219,9 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
       solve2(yr, zr, false);
     }
     if (lane == 0) w.sval[(size_t)b * w.m + j] = s;
-    if (regpath) { if (lane < c) alpha[lane] = yr; }
-    else for (int p = lane; p < c; p += WAVE) alpha[p] = vy[p];
+    double* lamD = w.lamD + ((size_t)b * w.m + j) * n;      // dense copy (zeros off the support) for the output-stationary Lambda Lambda'
+    if (regpath) { if (lane < c) { alpha[lane] = yr; lamD[idx[lane]] = yr; } }
+    else for (int p = lane; p < c; p += WAVE) { alpha[p] = vy[p]; lamD[idx[p]] = vy[p]; }
   } else {
     for (int e = lane; e < c * c; e += WAVE) {
       int p = e / c, q = e - p * c;
@@ -617,6 +627,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   double* Vr = w.Vrow + (size_t)b * NP * NP;
   const double sigma = 1.5 * sqrt(w.fro2[b]) + 1e-300;
   const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
+  STAMP_BEGIN();
   // ---- 1. G = (M + sigma I) V_prev  (or M + sigma I on the first call) ------------------------------------
   for (int e = tid; e < Np * ld; e += T) Gm[e] = 0.0;
   __syncthreads();
@@ -657,6 +668,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
     }
   }
   __syncthreads();
+  STAMP(0);
   // ---- 2. sweeps ---------------------------------------------------------------------------------------------
   {
     const int ngroups = T / LPP, grp = tid / LPP, lg = tid % LPP;
@@ -719,6 +731,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
     }
     if (tid == 0) w.sweeps[b] += sweeps;
   }
+  STAMP(1);
   // ---- 3. squared norms, eigenvectors for the next call ---------------------------------------------------------
   for (int t = wv; t < N; t += nw) {
     double a = 0.0;
@@ -732,6 +745,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
     Vr[(size_t)kk * NP + t] = Gm[(size_t)t * ld + kk] * rsqrt(ev[t]);
   }
   if (tid == 0) w.vvalid[b] = 1;
+  STAMP(2);
   // ---- 4. clip: rebuild either the defect or the kept part --------------------------------------------------------
   if (tid == 0) {
     int ndef = 0, nkeep = 0;
@@ -761,7 +775,9 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   double* Wout = w.W1 + (size_t)b * n * n;
   auto entry2 = [&](int i, int j) { return Mb[(size_t)j * NP + i]; };
   auto store = [&](int i, int j, double v, double) { Wout[(size_t)j * n + i] = v; Wout[(size_t)i * n + j] = v; };
+  STAMP(3);
   spectral_rebuild(Gm, ld, N, sel, wgt, s_nsel, s_base, entry2, store);
+  STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -924,7 +940,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const int n = w.n, k = w.k, m = w.m, rm = w.rmax;
   const int R = w.R[b], r = w.rr[b];
   auto tY = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.glob_scratch + (size_t)b * w.glob_scratch_stride; }();
-  double* tU = tY + (size_t)n * n;       // n*k   (tU, then the full-space U correction)
+  double* tU = tY + (size_t)n * m;       // n*k   (tU, then the full-space U correction); the first region is n*m >= n*n doubles
   double* tV = tU + (size_t)n * k;       // rm*k
   double* cvec = tV + (size_t)rm * k;    // Rmax
   double* mu = cvec + w.Rmax;            // Rmax
@@ -941,7 +957,37 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const double* W3V = w.W3V + (size_t)b * rm * k;
   const double* Q = w.Qb + (size_t)b * n * rm;
   const double rho = w.rho_b[b], rho_f = rho * w.rho_f_ratio, rx = w.relax, g = w.gamma;
-  // 1. cone + multiplicity part of the target
+  STAMP_BEGIN();
+  // 1. gamma/2 * Lambda Lambda', output-stationary and deterministic.  LDS path: the dense column-major copy of Lambda
+  //    (written by k_colprox, zero where a row is not observed) and the CSR column lists are staged in LDS -- in the
+  //    region that holds the target afterwards -- and every thread keeps its <= GL_MAXOUT sums in registers.
+  constexpr int GL_MAXOUT = 32;
+  double accLL[GL_MAXOUT];
+  const double* lamD = w.lamD + (size_t)b * m * n;
+  const bool ll_in_lds = USE_LDS && (n * n <= GL_MAXOUT * T);
+  if (ll_in_lds) {
+    double* LamS = tY;                                   // n*m doubles (region sized max(n*n, n*m) by the host)
+    int* ridx = (int*)(mu + w.Rmax);                     // nnz ints
+    for (int e = tid; e < n * m; e += T) LamS[e] = lamD[e];
+    for (int e = tid; e < w.nnz; e += T) ridx[e] = w.row_idx[e];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GL_MAXOUT; ++kk) {
+      const int e = tid + kk * T;
+      double acc = 0.0;
+      if (e < n * n) {
+        const int i2 = e % n, i = e / n;
+        for (int p = w.row_ptr[i]; p < w.row_ptr[i + 1]; ++p) {
+          const double* lj = LamS + (size_t)ridx[p] * n;
+          acc += lj[i] * lj[i2];
+        }
+      }
+      accLL[kk] = acc;
+    }
+    __syncthreads();
+  }
+  STAMP(8);
+  // 2. cone + multiplicity part of the target (+ the Lambda term)
   for (int e = tid; e < n * n; e += T) {
     double y = Y[e];
     tY[e] = rho_f * w.Ncnt[e] * y + rho * (rx * W1[e] + (1.0 - rx) * y + D1[e]) + rho * (y + (1.0 - rx) * D3[e] + rx * E3[e]);
@@ -952,16 +998,24 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   }
   for (int e = tid; e < R; e += T) mu[e] = lam[e] / rho;
   __syncthreads();
-  // 2. + gamma/2 * sum_j E_j' alpha alpha' E_j   (columns sequentially: no write conflicts inside one column)
-  const double* alpha = w.alpha + (size_t)b * w.nnz;
-  for (int j = 0; j < m; ++j) {
-    const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
-    for (int e = tid; e < c * c; e += T) {
-      int p = e % c, q = e / c;
-      tY[(size_t)w.col_idx[off + q] * n + w.col_idx[off + p]] += 0.5 * g * alpha[off + p] * alpha[off + q];
+  if (ll_in_lds) {
+#pragma unroll
+    for (int kk = 0; kk < GL_MAXOUT; ++kk) {
+      const int e = tid + kk * T;
+      if (e < n * n) { const int i2 = e % n, i = e / n; tY[(size_t)i * n + i2] += 0.5 * g * accLL[kk]; }
     }
-    __syncthreads();
+  } else {
+    for (int e = tid; e < n * n; e += T) {
+      const int i2 = e % n, i = e / n;            // consecutive threads -> consecutive i2: contiguous reads of Lambda[:, j]
+      double acc = 0.0;
+      for (int p = w.row_ptr[i]; p < w.row_ptr[i + 1]; ++p) {
+        const double* lj = lamD + (size_t)w.row_idx[p] * n;
+        acc += lj[i] * lj[i2];
+      }
+      tY[(size_t)i * n + i2] += 0.5 * g * acc;
+    }
   }
+  __syncthreads();
   for (int e = tid; e < n * n; e += T) tY[e] /= (rho * w.wY1[e]);
   for (int e = tid; e < n * k; e += T) {
     int i = e % n, j = e / n;
@@ -970,6 +1024,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     tU[e] = acc;
   }
   __syncthreads();
+  STAMP(9);
   // 3. c = A t - b
   const double* cutx = w.cutx + (size_t)b * w.Lmax * n;
   for (int rr = 0; rr < R; ++rr) {
@@ -991,10 +1046,12 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     if (tid == 0) cvec[rr] = tot - w.rrhs[(size_t)b * w.Rmax + rr];
   }
   __syncthreads();
+  STAMP(10);
   // 4. multipliers (mu = lam / rho)
   if (tid < WAVE) wave_nnqp(w.G + (size_t)b * w.Rmax * w.Rmax, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid);
   __syncthreads();
   for (int e = tid; e < R; e += T) lam[e] = rho * mu[e];
+  STAMP(11);
   // 5. U-space correction  corr = A_U' mu / 2  (n x k, stored over tU)  and Vn = tV - Q' corr
   for (int e = tid; e < n * k; e += T) {
     int i = e % n, j = e / n;
@@ -1030,37 +1087,43 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     for (int a = 0; a < r; ++a) acc += Q[(size_t)a * n + i] * tV[(size_t)j * rm + a];
     U[e] = acc;
   }
-  // 6. Y
-  for (int e = tid; e < n * n; e += T) {
-    int i = e % n, j = e / n;
-    if (i < j) continue;
-    double corr = 0.0;
+  STAMP(12);
+  // 6. Y: every thread owns one entry (all quantities are symmetric, so no mirrored stores: coalesced reads and writes);
+  //    the active cut rows are staged once in LDS
+  __shared__ int s_nact; __shared__ int s_act[NNQP_PMAX]; __shared__ double s_mu[NNQP_PMAX]; __shared__ double s_trace_mu;
+  if (tid == 0) {
+    int c2 = 0; double tm = 0.0;
     for (int rr = 0; rr < R; ++rr) {
-      double mv = mu[rr];
+      const double mv = mu[rr];
       if (mv == 0.0) continue;
-      int kind = w.rkind[(size_t)b * w.Rmax + rr];
-      if (kind == ROW_TRACE) { if (i == j) corr += mv; }
-      else if (kind == ROW_CUT) { const double* x = cutx + (size_t)w.rcut[(size_t)b * w.Rmax + rr] * n; corr += mv * x[i] * x[j]; }
+      const int kind = w.rkind[(size_t)b * w.Rmax + rr];
+      if (kind == ROW_TRACE) tm += mv;
+      else if (kind == ROW_CUT && c2 < NNQP_PMAX) { s_act[c2] = w.rcut[(size_t)b * w.Rmax + rr]; s_mu[c2] = mv; ++c2; }
     }
-    const size_t a1 = (size_t)j * n + i, a2 = (size_t)i * n + j;
-    double t = 0.5 * (tY[a1] + tY[a2]);
-    double yn = t - corr / w.wY1[a1];
-    double yold = Y[a1];
-    double w1 = W1[a1], e3 = E3[a1], d3 = D3[a1];
-    double d1n = D1[a1] + rx * w1 + (1.0 - rx) * yold - yn;
-    double w3y = yold - d3 + e3;                       // projection output of the small-cone block
-    double d3n = (1.0 - rx) * d3 + yold + rx * e3 - yn;
-    D1[a1] = d1n; D1[a2] = d1n; D3[a1] = d3n; D3[a2] = d3n;
-    double mult = (i == j) ? 1.0 : 2.0;
-    {
-      const double mv = yn - d1n;                      // next input of the cone block
-      Mb[(size_t)j * NP + i] = mv; Mb[(size_t)i * NP + j] = mv;
-      fr2 += mult * mv * mv;
-    }
-    rp2 += mult * ((w1 - yn) * (w1 - yn) + (w3y - yn) * (w3y - yn));
-    rd2 += mult * (yn - yold) * (yn - yold);
-    Yp[a1] = yold; Yp[a2] = yold; Y[a1] = yn; Y[a2] = yn;
+    s_nact = c2; s_trace_mu = tm;
   }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += T) {
+    const int i = e % n, j = e / n;
+    double corr = (i == j) ? s_trace_mu : 0.0;
+    for (int a = 0; a < s_nact; ++a) { const double* x = cutx + (size_t)s_act[a] * n; corr += s_mu[a] * (x[i] * x[j]); }   // (x_i x_j) first: exactly symmetric in (i, j)
+    const size_t a1 = (size_t)j * n + i, a2 = (size_t)i * n + j;
+    const double t = 0.5 * (tY[a1] + tY[a2]);
+    const double yn = t - corr / w.wY1[a1];
+    const double yold = Y[a1];
+    const double w1 = W1[a1], e3 = E3[a1], d3 = D3[a1];
+    const double d1n = D1[a1] + rx * w1 + (1.0 - rx) * yold - yn;
+    const double w3y = yold - d3 + e3;                 // projection output of the small-cone block
+    const double d3n = (1.0 - rx) * d3 + yold + rx * e3 - yn;
+    D1[a1] = d1n; D3[a1] = d3n;
+    const double mv = yn - d1n;                        // next input of the cone block
+    Mb[(size_t)j * NP + i] = mv;
+    fr2 += mv * mv;
+    rp2 += (w1 - yn) * (w1 - yn) + (w3y - yn) * (w3y - yn);
+    rd2 += (yn - yold) * (yn - yold);
+    Yp[a1] = yold; Y[a1] = yn;
+  }
+  STAMP(13);
   rp2 = block_sum(rp2, red);
   rd2 = block_sum(rd2, red);
   fr2 = block_sum(fr2, red);
