@@ -458,11 +458,11 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       const int Np2 = (n + 1) & ~1;
       int lpp = 16; while (lpp > 4 && lpp * (Np2 / 2) > 512) lpp >>= 1;
       int rpl = (((n + lpp - 1) / lpp) + 1) & ~1, Nrp = rpl * lpp, ldw = Nrp + 2;
-      h->ws_lds = ((size_t)Np2 * ldw + 2 * Np2) * 8 + (size_t)Np2 * 4 + 64;
+      h->ws_lds = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
       h->ws_use_lds = h->ws_lds <= OMC_MAX_DYN_LDS;
       if (!h->ws_use_lds) {
         lpp = 16; rpl = (((n + 15) / 16) + 1) & ~1; Nrp = rpl * 16; ldw = Nrp + 2;
-        const size_t need = ((size_t)Np2 * ldw + 2 * Np2) * 8 + (size_t)Np2 * 4 + 64;
+        const size_t need = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
         if (need / 8 + 8 > w.cone_scratch_stride) {
           w.cone_scratch_stride = need / 8 + 8;
           ENS(h->bcone, sB * w.cone_scratch_stride * 8);

@@ -440,7 +440,7 @@ __device__ __forceinline__ void spectral_rebuild(const double* Gm, int ld, int N
 
 // common front end: load the symmetrised matrix into Gm (Np x ld), shift, Jacobi, squared column norms -> ev
 template <class EntryF>
-__device__ __forceinline__ double eig_frontend(double* Gm, double* ev, int N, int Np, int ld, EntryF entry, double* red, int* s_cnt, int* sweeps_out) {
+__device__ __forceinline__ double eig_frontend(double* Gm, double* ev, int N, int Np, int ld, EntryF entry, double* red, int* s_cnt, int* sweeps_out, double tau_in = 1e-14) {
   const int tid = threadIdx.x, T = blockDim.x;
   double fro = 0.0;
   for (int e = tid; e < Np * Np; e += T) {
@@ -456,7 +456,7 @@ __device__ __forceinline__ double eig_frontend(double* Gm, double* ev, int N, in
   int lpp = 64;
   while (lpp > 1 && lpp * (Np >> 1) > T) lpp >>= 1;
   if (lpp > 16) lpp = 16;
-  const double tau = fmax(1e-14, 2.2e-16 * N);
+  const double tau = tau_in;
   int sweeps;
   if (lpp >= 4 && (N + lpp - 1) / lpp <= JROWS) {
     // ev doubles as the norm cache during the sweeps (recomputed below)
@@ -496,7 +496,8 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
   auto wgt = ev + Np;
   int* sel = (int*)(wgt + Np);
   auto entry = [&](int i, int j) { return cone_M_entry(w, b, mode, i, j); };
-  const double sigma = eig_frontend(Gm, ev, N, Np, ld, entry, red, &s_cnt, w.sweeps + b);
+  // eigenvalues only (certificate): their error is second order in the residual cross products, 1e-9 is ample
+  const double sigma = eig_frontend(Gm, ev, N, Np, ld, entry, red, &s_cnt, w.sweeps + b, (mode == CONE_EVALS) ? 1e-9 : 1e-14);
   if (mode == CONE_EVALS) {
     if (tid == 0) {
       double best[8]; int kk = (k < 8) ? k : 8;
@@ -629,8 +630,10 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
   STAMP_BEGIN();
   // ---- 1. G = (M + sigma I) V_prev  (or M + sigma I on the first call) ------------------------------------
+  STAMP(5);
   for (int e = tid; e < Np * ld; e += T) Gm[e] = 0.0;
   __syncthreads();
+  STAMP(6);
   if (!w.vvalid[b]) {
     for (int e = tid; e < N * N; e += T) {
       int i = e % N, j = e / N;
@@ -640,30 +643,38 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
     const int nt = NP >> 4;
     const int K4 = (N + 3) & ~3;
     const int li = lane & 15, lk = lane >> 4;
+    // software pipeline of depth PF k-steps with NO conditionals inside the K loop (a guarded load makes hipcc drain
+    // vmcnt before every MFMA): K runs over the whole zero-padded NP (a multiple of 16 = 4*PF), the prefetch index wraps
+    constexpr int PF = 4;
     for (int tile = wv; tile < nt * nt; tile += nw) {
       const int ti = tile % nt, tj = tile / nt;
       const int i0 = ti << 4, j0 = tj << 4;
       double4v acc = {0.0, 0.0, 0.0, 0.0};
-      const int ia = i0 + li;
-      // software pipeline: operands of step k0+4 are in flight while the MFMA of step k0 issues
-      double a_n = Mb[(size_t)lk * NP + ia] + ((ia == lk) ? sigma : 0.0);
-      double b_n = Vr[(size_t)lk * NP + j0 + li];
-      for (int k0 = 0; k0 < K4; k0 += 4) {
-        const double a = a_n, bv = b_n;
-        const int kn = k0 + 4 + lk;
-        if (k0 + 4 < K4) {
-          a_n = Mb[(size_t)kn * NP + ia] + ((ia == kn) ? sigma : 0.0);
-          b_n = Vr[(size_t)kn * NP + j0 + li];
-        }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
-      }
-      const int col = j0 + li;
-      if (col < N) {
+      const int ia = i0 + li, jb = j0 + li;
+      const double* Ma = Mb + ia;
+      const double* Vb = Vr + jb;
+      double aq[PF], bq[PF];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = i0 + lk + 4 * r;
-          if (row < N) Gm[(size_t)col * ld + row] = acc[r];
+      for (int u = 0; u < PF; ++u) {
+        const int kk = 4 * u + lk;
+        aq[u] = Ma[(size_t)kk * NP];
+        bq[u] = Vb[(size_t)kk * NP];
+      }
+      for (int k0 = 0; k0 < NP; k0 += 4 * PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          // the shift is added when the operand is CONSUMED: touching the prefetched value earlier would stall on it
+          const double a = aq[u] + ((ia == k0 + 4 * u + lk) ? sigma : 0.0), bv = bq[u];
+          int kn = k0 + 4 * (PF + u) + lk;
+          kn = (kn < NP) ? kn : kn - NP;                 // wrapped prefetch of the last chunk is never used
+          aq[u] = Ma[(size_t)kn * NP];
+          bq[u] = Vb[(size_t)kn * NP];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
         }
+      }
+      if (jb < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = i0 + lk + 4 * r; if (row < N) Gm[(size_t)jb * ld + row] = acc[r]; }
       }
     }
   }
@@ -747,30 +758,36 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   if (tid == 0) w.vvalid[b] = 1;
   STAMP(2);
   // ---- 4. clip: rebuild either the defect or the kept part --------------------------------------------------------
+  // eigenvalues in parallel (the square roots), then one lane compacts the selected columns (integer work only)
+  double* lamv_s = (double*)(sel + Np + (Np & 1));
+  for (int t = tid; t < N; t += T) lamv_s[t] = sqrt(ev[t]) - sigma;
+  __syncthreads();
   if (tid == 0) {
     int ndef = 0, nkeep = 0;
     for (int t = 0; t < N; ++t) {
-      double lamv = sqrt(ev[t]) - sigma;
+      const double lamv = lamv_s[t];
       if (lamv < 0.0 || lamv > 1.0) ++ndef;
       if (lamv > 0.0) ++nkeep;
     }
     int c = 0;
     if (ndef <= nkeep) {
       for (int t = 0; t < N; ++t) {
-        double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
-        if (lamv < 0.0) { sel[c] = t; wgt[c] = -lamv / nu2; ++c; }
-        else if (lamv > 1.0) { sel[c] = t; wgt[c] = -(lamv - 1.0) / nu2; ++c; }
+        const double lamv = lamv_s[t];
+        if (lamv < 0.0) { sel[c] = t; wgt[c] = -lamv; ++c; }
+        else if (lamv > 1.0) { sel[c] = t; wgt[c] = -(lamv - 1.0); ++c; }
       }
       s_base = 1.0;
     } else {
       for (int t = 0; t < N; ++t) {
-        double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
-        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, 1.0) / nu2; ++c; }
+        const double lamv = lamv_s[t];
+        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, 1.0); ++c; }
       }
       s_base = 0.0;
     }
     s_nsel = c;
   }
+  __syncthreads();
+  for (int c2 = tid; c2 < s_nsel; c2 += T) wgt[c2] /= ev[sel[c2]];      // weight / nu^2
   __syncthreads();
   double* Wout = w.W1 + (size_t)b * n * n;
   auto entry2 = [&](int i, int j) { return Mb[(size_t)j * NP + i]; };
