@@ -73,6 +73,11 @@ typedef struct omc_relax_params {
   int reference_quirk_q1; /* 1: linear3/right piece exactly as OMC.jl:1675; 0: secant        (1)     */
   int breakpoints;     /* OMC_SMALLEST_1_EIGVEC / _2_ : which separation vector to return    (1)     */
   int stall_checks;    /* stop with OMC_SLOW_PROGRESS after this many stationary checks      (8)     */
+  int bump_max;        /* penalty bumps per node (0 = off): rho *= bump_factor when the primal   (3)     */
+  double bump_ratio;   /*   residual exceeds bump_ratio x the dual residual at a check ...      (8.0)   */
+  double bump_factor;  /*                                                                       (4.0)   */
+  int bump_after;      /*   ... from this iteration on, at least bump_window checks apart       (200)   */
+  int bump_window;     /*                                                                       (8)     */
 } omc_relax_params;
 
 void omc_relax_params_default(omc_relax_params* p);
@@ -157,6 +162,8 @@ int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded
 int omc_last_solver_info(omc_instance* h, double* info);
 /* diagnostic builds (-DOMC_STAMPS) only: accumulated s_memtime ticks per kernel phase of node 0; zeros otherwise */
 int omc_debug_stamps(omc_instance* h, double* out32);
+/* last primal / dual ADMM residuals of every node of the staged batch (diagnostics) */
+int omc_debug_residuals(omc_instance* h, double* rp, double* rd);
 int omc_last_kernel_stats(omc_instance* h, int64_t* launches /*NCLASS*/, double* ms /*NCLASS*/,
                           int64_t* units /*NCLASS*/);
 

@@ -91,6 +91,7 @@ void omc_relax_params_default(omc_relax_params* p) {
   p->eps_gap = 1e-6; p->eps_feas = 1e-7; p->max_iters = 3000; p->check_every = 25;
   p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
+  p->bump_max = 3; p->bump_ratio = 8.0; p->bump_factor = 4.0; p->bump_after = 200; p->bump_window = 8;
 }
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
@@ -353,6 +354,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   }
   if (!(w.rho > 0.0)) w.rho = 1.0;
   w.rho_f_ratio = P.rho_f_ratio;
+  w.bump_max = P.bump_max; w.bump_ratio = P.bump_ratio; w.bump_factor = P.bump_factor; w.bump_after = P.bump_after;
+  w.bump_gap = P.bump_window * std::max(1, P.check_every);
   {
     std::vector<double> hr(B, w.rho);
     if (h->rho_scale_per_node.size() == (size_t)B)
@@ -378,7 +381,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   ENS(h->balpha, sB * h->nnz * 8); ENS(h->balphaX, sB * h->nnz * 8); ENS(h->bsval, sB * m * 8);
   ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8 + 32 * 8);
   ENS(h->bG, sB * Rmax * Rmax * 8); ENS(h->blam, sB * Rmax * 8);
-  ENS(h->bscal, sB * 15 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 6 * sizeof(int));
+  ENS(h->bscal, sB * 16 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 8 * sizeof(int));
   w.np16 = (n + 15) & ~15;
   ENS(h->bMbuf, sB * w.np16 * w.np16 * 8); ENS(h->bVrow, sB * w.np16 * w.np16 * 8);
   ENS(h->blamD, sB * m * n * 8);
@@ -399,10 +402,10 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   double* sc = h->bscal.as<double>();
   w.obj = sc; w.objout = sc + sB; w.lb = sc + 2 * sB; w.c0 = sc + 3 * sB; w.evsum = sc + 4 * sB; w.cpen = sc + 5 * sB;
   w.cst = sc + 6 * sB; w.rp = sc + 7 * sB; w.rd = sc + 8 * sB; w.lmin = sc + 9 * sB;  // lmin uses 2B (slots 9,10)
-  w.objprev = sc + 11 * sB; w.lbprev = sc + 12 * sB; w.fro2 = sc + 13 * sB;
+  w.objprev = sc + 11 * sB; w.lbprev = sc + 12 * sB; w.fro2 = sc + 13 * sB; w.bfac = sc + 14 * sB;
   w.bx = h->bbx.as<double>();
   int* ip = h->bint.as<int>();
-  w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB; w.vvalid = ip + 5 * sB;
+  w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB; w.vvalid = ip + 5 * sB; w.nbump = ip + 6 * sB; w.lastbump = ip + 7 * sB;
   // Q upload
   {
     std::vector<double> hQ(sB * n * rmax, 0.0);
@@ -545,6 +548,7 @@ int omc_relax_solve(omc_instance* h) {
         omc_launch_check_build(&w, s);
         omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
         omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : (last ? OMC_ST_SLOW : 0), s);
+        if (w.bump_max > 0) omc_launch_rho_rescale(&w, s);
       });
       HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * B, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
@@ -751,6 +755,13 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   HIPCHK(hipGetLastError());
   const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (solve_time) for (int b = 0; b < B; ++b) solve_time[b] = el;
+  return 0;
+}
+
+int omc_debug_residuals(omc_instance* h, double* rp, double* rd) {
+  if (!h || !rp || !rd || !h->ws.rp) return fail(OMC_ERR_ARGUMENT, "nothing staged");
+  HIPCHK(hipMemcpy(rp, h->ws.rp, 8 * (size_t)h->ws.B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rd, h->ws.rd, 8 * (size_t)h->ws.B, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -29,7 +29,10 @@ struct OmcWS {
   int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16, max_sweeps;
   // parameters
   double gamma, rho, rho_f_ratio, relax, eps_gap, eps_feas, sumA2, jacobi_tau;   // rho: batch default (rho_b holds the per-node value)
-  const double* rho_b;    // B: ADMM penalty of node b
+  double* rho_b;          // B: ADMM penalty of node b (bumped on the device)
+  double* bfac;           // B: rescale factor decided at the last check (1 = none)
+  int *nbump, *lastbump;  // B
+  int bump_max, bump_after, bump_gap; double bump_ratio, bump_factor;
   // instance (device, read-only)
   const int* col_ptr;     // m+1
   const int* col_idx;     // nnz: observed rows of each column, ascending
@@ -89,6 +92,7 @@ void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, 
 void omc_launch_check_zero(const OmcWS* w, hipStream_t s);
 void omc_launch_check_build(const OmcWS* w, hipStream_t s);
 void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);
+void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s);
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s);
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s);
 void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,

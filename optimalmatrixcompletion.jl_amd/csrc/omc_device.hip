@@ -80,7 +80,7 @@ __global__ void k_setup(OmcWS w) {
   const int R = w.R[b];
   for (int e = tid; e < w.Rmax; e += T) w.lam[(size_t)b * w.Rmax + e] = 0.0;
   if (tid == 0) {
-    w.done[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0;
+    w.done[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0; w.nbump[b] = 0; w.lastbump[b] = 0; w.bfac[b] = 1.0;
     w.obj[b] = 1e300; w.objout[b] = 1e300; w.objprev[b] = 1e300; w.lbprev[b] = -1e300; w.lb[b] = -1e300; w.rp[b] = 1e300; w.rd[b] = 1e300;
   }
   // Gram matrix for rho = 1
@@ -830,6 +830,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   const double* Y = w.Y + (size_t)b * n * n;
   const double* D3 = w.D3 + (size_t)b * n * n;
   const double* Vt = w.Vt + (size_t)b * rm * k;
+  STAMP_BEGIN();
   // T1 = (Y - D3) Q   or  Y Q
   for (int e = tid; e < n * r; e += T) {
     int i = e % n, a = e / n;
@@ -839,6 +840,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
     T1[(size_t)a * n + i] = acc;
   }
   __syncthreads();
+  STAMP(16);
   // M3
   for (int e = tid; e < N3 * N3; e += T) {
     int i = e % N3, j = e / N3;
@@ -850,6 +852,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
     M3[(size_t)j * ld3 + i] = v;
   }
   __syncthreads();
+  STAMP(17);
   if (N3 == 0) return;
   auto entry = [&](int i, int j) { return M3[(size_t)j * ld3 + i]; };
   const double sigma = eig_frontend(Gm, ev, N3, Np, ld, entry, red, &s_cnt, nullptr);
@@ -888,6 +891,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
     }
     return;
   }
+  STAMP(18);
   // SMALL_PROJ: Q3 = P3 - M3 = sum_{lam<0} |lam| v v'   (or P3 directly when fewer positive eigenvalues)
   if (tid == 0) {
     int npos = 0, nneg = 0;
@@ -920,6 +924,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   spectral_rebuild(Gm, ld, N3, sel, wgt, s_nsel, s_base, entry, store);
   __syncthreads();
   __threadfence_block();
+  STAMP(19);
   // E3 = Q dS Q'  (n x n): T1 <- Q dS (n x r), then E3 = T1 Q'
   for (int e = tid; e < n * r; e += T) {
     int i = e % n, a = e / n;
@@ -936,6 +941,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
     for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Q[(size_t)a * n + j];
     E3[(size_t)j * n + i] = acc; E3[(size_t)i * n + j] = acc;
   }
+  STAMP(20);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1234,7 +1240,37 @@ __global__ void k_check_final(OmcWS w, int last) {
     const bool okgap = (obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && w.rp[b] <= 10.0 * w.eps_feas * sqrt(Nk);
     w.done[b] = 1; w.status[b] = okgap ? OMC_ST_OPTIMAL : OMC_ST_SLOW; return;
   }
-  if (last) { w.done[b] = 1; w.status[b] = last; }
+  if (last) { w.done[b] = 1; w.status[b] = last; return; }
+  // penalty bump: crawling nodes with active cuts show rp >> rd
+  w.bfac[b] = 1.0;
+  if (w.bump_max > 0 && w.iters[b] >= w.bump_after && w.nbump[b] < w.bump_max && w.iters[b] - w.lastbump[b] >= w.bump_gap &&
+      w.rp[b] > w.bump_ratio * w.rd[b]) {
+    w.bfac[b] = w.bump_factor; w.rho_b[b] *= w.bump_factor; w.nbump[b] += 1; w.lastbump[b] = w.iters[b];
+  }
+}
+
+// scaled duals follow the penalty: D <- D / factor  (G1, wY1 and the multipliers lambda are penalty-free)
+__global__ void __launch_bounds__(256) k_rho_rescale(OmcWS w) {
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b]) return;
+  const double f = w.bfac[b];
+  if (f == 1.0) return;
+  const double inv = 1.0 / f;
+  const int n = w.n, k = w.k, rm = w.rmax;
+  for (int e = tid; e < n * n; e += T) { w.D1[(size_t)b * n * n + e] *= inv; w.D3[(size_t)b * n * n + e] *= inv; }
+  for (int e = tid; e < rm * k; e += T) w.D3V[(size_t)b * rm * k + e] *= inv;
+  for (int e = tid; e < k * k; e += T) w.D3T[(size_t)b * k * k + e] *= inv;
+  // the cone input buffer holds Y - D1: rebuild it with the rescaled dual
+  const int NP = w.np16;
+  double fr2 = 0.0;
+  __shared__ double red[32];
+  for (int e = tid; e < n * n; e += T) {
+    const int i = e % n, j = e / n;
+    const double mv = w.Y[(size_t)b * n * n + e] - w.D1[(size_t)b * n * n + e];
+    w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
+  }
+  fr2 = block_sum(fr2, red);
+  if (tid == 0) { w.fro2[b] = fr2; w.bfac[b] = 1.0; }
 }
 
 __global__ void k_zero_check(OmcWS w) {
@@ -1338,6 +1374,7 @@ void omc_launch_check_build(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(
 void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s) {
   hipLaunchKernelGGL(k_check_final, dim3((w->B + 63) / 64), dim3(64), 0, s, *w, last);
 }
+void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_rho_rescale, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s) { hipLaunchKernelGGL(k_make_X, dim3(64, w->B), dim3(256), 0, s, *w, X); }
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s) {
   hipLaunchKernelGGL(k_make_Theta, dim3(64, w->B), dim3(256), 0, s, *w, X, Th);

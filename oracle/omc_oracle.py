@@ -450,6 +450,12 @@ class RelaxParams:
     time_limit: float = 3600.0
     reference_quirk_q1: bool = True
     rho_init: float = 0.0        # > 0: start from this penalty (e.g. the parent's final rho)
+    bump: int = 1                # 1: multiply rho by bump_factor when the primal residual exceeds bump_ratio x the dual residual
+    bump_factor: float = 4.0
+    bump_window: int = 8         # checks between two bumps
+    bump_after: int = 200        # first iteration at which a bump may happen
+    bump_max: int = 3
+    bump_ratio: float = 8.0
 
 
 def _prox_columns(inst, Yx, alpha, svals, rho_f):
@@ -643,6 +649,7 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
     hist = []
     it = 0; rx = p.relax
     stall = 0; obj_prev = math.inf; lb_prev = -math.inf
+    n_bumps = 0; last_bump = 0
     Q3 = np.zeros((r + k, r + k))
     for it in range(1, p.max_iters + 1):
         rho_f = rho * p.rho_f_ratio
@@ -701,18 +708,14 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
             if time.time() - t0 > p.time_limit:
                 status = OMC_TIME_LIMIT
                 break
-            if p.adapt and it in ADAPT_AT:
-                # residual balancing (normalised as in OSQP): primal rp / ||z||  vs  dual rho*rd / ||gradient scale||
-                zn = math.sqrt(float(np.linalg.norm(Y) ** 2 + 2.0 * np.linalg.norm(Vt) ** 2 + k))
-                dn = rho * math.sqrt(float(np.linalg.norm(D1) ** 2 + np.linalg.norm(D3) ** 2
-                                           + 2.0 * np.linalg.norm(D3V) ** 2 + np.linalg.norm(D3T) ** 2))
-                gn = max(dn, 0.5 * g * float(np.linalg.norm(LL)))
-                if gn > 0 and rd > 0 and rp > 0:
-                    ratio = (rp / zn) / (rho * rd / gn)
-                    if ratio > 2.0 or ratio < 0.5:
-                        fac = min(10.0, max(0.1, math.sqrt(ratio)))
-                        rho *= fac
-                        D1 /= fac; D3 /= fac; D3V /= fac; D3T /= fac
+            # penalty bump: nodes with active cuts want a larger rho than the root-tuned one.  Signal (measured on config 2):
+            # crawling nodes sit at rp/rd = 10..200 at iteration 400, healthy ones at 0.4..4
+            if (p.bump and it >= p.bump_after and n_bumps < p.bump_max and it - last_bump >= p.check_every * p.bump_window
+                    and rp > p.bump_ratio * rd):
+                fac = p.bump_factor
+                rho *= fac
+                D1 /= fac; D3 /= fac; D3V /= fac; D3T /= fac
+                n_bumps += 1; last_bump = it
     obj, Lam = inst.f_value(Y, want=True)
     X = inst.X_of(Y, Lam)
     U = recover_U(Y, Q, Vt)
