@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--depth", type=int, default=int(os.environ.get("OMC_BENCH_DEPTH", 6)), help="frontier depth: B = 2^depth nodes per GPU")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("OMC_BENCH_DEPTH", 8)), help="frontier depth: 2^depth nodes per GPU per step")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("OMC_BENCH_SLOTS", 128)), help="nodes relaxed concurrently per GPU (continuous batching)")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--cpu-nodes", type=int, default=2, help="nodes relaxed by the CPU oracle for cpu_baseline (rank 0, N=1 only)")
     args = ap.parse_args()
@@ -49,7 +50,7 @@ def main():
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
     eng = omc_amd.Engine(A, mask, gamma, k, device=local)
     rho_scale, tune_log = bnb.autotune_rho_scale(eng, cfg["cut_type"])
-    P = omc_amd.default_params(rho_scale=rho_scale)
+    P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots)
     # every rank builds the same frontier (deterministic) and keeps a shard-sized batch: rank r takes a rotated copy so
     # that ranks do not all hold the identical node order
     nodes, _ = bnb.expand_frontier(eng, args.depth, cfg["cut_type"], params=P)
@@ -128,7 +129,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config {args.config}: {n}x{m} rank-{k}, gamma=80, 20% observed, {cfg['cut_type']} cuts, smallest_1_eigvec; "
-                                   f"batch of {B} depth-{args.depth} frontier nodes per GPU", "nodes_per_gpu": B, "rho_scale": rho_scale,
+                                   f"{B} depth-{args.depth} frontier nodes per GPU per step through {min(args.slots, B)} slots (continuous batching)", "nodes_per_gpu": B, "slots": min(args.slots, B), "rho_scale": rho_scale,
                        "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
                        "status_counts": {"optimal": int(status[0]), "slow_progress": int(status[1]), "time_limit": int(status[2]), "infeasible": int(status[3])},
                        "jacobi_sweeps_last_step": info["jacobi_sweeps"], "instance_sha256": data.instance_sha256(A, mask)[:16]},

@@ -78,6 +78,7 @@ typedef struct omc_relax_params {
   double bump_factor;  /*                                                                       (4.0)   */
   int bump_after;      /*   ... from this iteration on, at least bump_window checks apart       (200)   */
   int bump_window;     /*                                                                       (8)     */
+  int slots;           /* nodes relaxed concurrently (continuous batching); 0 = min(B, 256)       (0)     */
 } omc_relax_params;
 
 void omc_relax_params_default(omc_relax_params* p);

@@ -22,7 +22,7 @@ class RelaxParams(C.Structure):
     _fields_ = [("eps_gap", C.c_double), ("eps_feas", C.c_double), ("max_iters", C.c_int), ("check_every", C.c_int),
                 ("rho_scale", C.c_double), ("rho_f_ratio", C.c_double), ("relax", C.c_double), ("time_limit", C.c_double),
                 ("reference_quirk_q1", C.c_int), ("breakpoints", C.c_int), ("stall_checks", C.c_int), ("bump_max", C.c_int), ("bump_ratio", C.c_double),
-                ("bump_factor", C.c_double), ("bump_after", C.c_int), ("bump_window", C.c_int)]
+                ("bump_factor", C.c_double), ("bump_after", C.c_int), ("bump_window", C.c_int), ("slots", C.c_int)]
 
 
 class OmcError(RuntimeError):

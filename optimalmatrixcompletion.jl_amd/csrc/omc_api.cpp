@@ -68,8 +68,9 @@ struct omc_instance {
   omc_relax_params params{};
   bool staged = false;
   int cone_use_lds = 0, glob_use_lds = 0, small_use_lds = 0; size_t cone_lds = 0, glob_lds = 0, small_lds = 0;
-  double last_solve_seconds = 0; long long total_sweeps = 0;
-  std::vector<double> rho_scale_per_node; DevBuf brho, blamD;
+  double last_solve_seconds = 0; long long total_sweeps = 0; int last_iters_total = 0;
+  std::vector<double> rho_scale_per_node; DevBuf brho, brhon, blamD, bslotint, boY, boU, boal, bobx, boscal, boint;
+  int Btot = 0;
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
   size_t nnz_rows() const { return row_idx.size(); }
@@ -91,7 +92,7 @@ void omc_relax_params_default(omc_relax_params* p) {
   p->eps_gap = 1e-6; p->eps_feas = 1e-7; p->max_iters = 3000; p->check_every = 25;
   p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
-  p->bump_max = 3; p->bump_ratio = 8.0; p->bump_factor = 4.0; p->bump_after = 200; p->bump_window = 8;
+  p->bump_max = 3; p->bump_ratio = 8.0; p->bump_factor = 4.0; p->bump_after = 200; p->bump_window = 8; p->slots = 0;
 }
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
@@ -182,7 +183,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
-                   &h->brho, &h->blamD, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
+                   &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -343,7 +344,11 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   // ---- workspace -------------------------------------------------------------------------------------
   OmcWS& w = h->ws;
   memset(&w, 0, sizeof(w));
-  w.B = B; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
+  // continuous batching: S slots relax B nodes; a slot that finishes is harvested and re-used for the next pending node
+  int S = (P.slots > 0) ? std::min(P.slots, B) : std::min(B, 256);
+  if (getenv("OMC_SLOTS")) S = std::max(1, std::min(B, atoi(getenv("OMC_SLOTS"))));
+  h->Btot = B;
+  w.B = S; w.Btot = B; w.max_iters = P.max_iters; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
   w.jacobi_tau = getenv("OMC_JACOBI_TAU") ? atof(getenv("OMC_JACOBI_TAU")) : 0.0;
   w.max_sweeps = getenv("OMC_DEBUG_MAX_SWEEPS") ? atoi(getenv("OMC_DEBUG_MAX_SWEEPS")) : 30;
   w.breakpoints = P.breakpoints; w.stall_checks = P.stall_checks > 0 ? P.stall_checks : 1000000;
@@ -361,7 +366,10 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     if (h->rho_scale_per_node.size() == (size_t)B)
       for (int b = 0; b < B; ++b) hr[b] = w.rho / P.rho_scale * h->rho_scale_per_node[b];
     h->rho_scale_per_node.clear();
-    int r0 = upload(h->brho, hr.data(), sizeof(double) * B, h->stream); if (r0) return r0;
+    int r0 = upload(h->brhon, hr.data(), sizeof(double) * B, h->stream); if (r0) return r0;
+    HIPCHK(hipStreamSynchronize(h->stream));          // hr dies with this block: the copy must have read it
+    w.rho_node = h->brhon.as<double>();
+    r0 = h->brho.ensure(sizeof(double) * (size_t)S); if (r0) return r0;
     w.rho_b = h->brho.as<double>();
   }
   w.relax = P.relax; w.eps_gap = P.eps_gap; w.eps_feas = P.eps_feas;
@@ -373,7 +381,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   w.Ncnt = h->dNcnt.as<double>(); w.wY1 = h->dwY.as<double>();
   w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>();
 #define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)
-  const size_t sB = (size_t)B;
+  const size_t sB = (size_t)S;      // state arrays: one per slot
+  const size_t sN = (size_t)B;      // descriptor and output arrays: one per node
   ENS(h->bY, sB * n * n * 8); ENS(h->bYp, sB * n * n * 8); ENS(h->bU, sB * n * k * 8);
   ENS(h->bD1, sB * n * n * 8); ENS(h->bD3, sB * n * n * 8); ENS(h->bW1, sB * n * n * 8); ENS(h->bE3, sB * n * n * 8);
   ENS(h->bdS, sB * rmax * rmax * 8);
@@ -406,17 +415,33 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   w.bx = h->bbx.as<double>();
   int* ip = h->bint.as<int>();
   w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB; w.vvalid = ip + 5 * sB; w.nbump = ip + 6 * sB; w.lastbump = ip + 7 * sB;
+  {
+    ENS(h->bslotint, sB * 3 * sizeof(int));
+    int* si = h->bslotint.as<int>();
+    w.node_of = si; w.init = si + sB; w.fin = si + 2 * sB;
+    std::vector<int> hs(sB * 3);
+    for (size_t b = 0; b < sB; ++b) { hs[b] = (int)b; hs[sB + b] = 1; hs[2 * sB + b] = 1; }   // identity map, every slot initialises
+    HIPCHK(hipMemcpyAsync(si, hs.data(), sizeof(int) * hs.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));          // hs dies with this block
+    ENS(h->boY, sN * n * n * 8); ENS(h->boU, sN * n * k * 8); ENS(h->boal, sN * h->nnz * 8); ENS(h->bobx, sN * n * 8);
+    ENS(h->boscal, sN * 5 * 8); ENS(h->boint, sN * 2 * sizeof(int));
+    w.oY = h->boY.as<double>(); w.oU = h->boU.as<double>(); w.oalphaX = h->boal.as<double>(); w.obx = h->bobx.as<double>();
+    double* os = h->boscal.as<double>();
+    w.oobj = os; w.olb = os + sN; w.olmin = os + 2 * sN; w.orho = os + 4 * sN;
+    w.ostatus = h->boint.as<int>(); w.oiters = h->boint.as<int>() + sN;
+  }
   // Q upload
   {
-    std::vector<double> hQ(sB * n * rmax, 0.0);
+    std::vector<double> hQ(sN * n * rmax, 0.0);
     for (int b = 0; b < B; ++b) memcpy(&hQ[(size_t)b * n * rmax], Qn[b].data(), sizeof(double) * Qn[b].size());
     if ((rc_ = upload(h->bQb, hQ.data(), sizeof(double) * hQ.size(), h->stream))) return rc_;
     if ((rc_ = upload(h->brr, rrv.data(), sizeof(int) * B, h->stream))) return rc_;
+    HIPCHK(hipStreamSynchronize(h->stream));          // hQ dies with this block
     w.Qb = h->bQb.as<double>(); w.rr = h->brr.as<int>();
   }
   // rows upload (padded to Rmax)
-  std::vector<int> hR(B), hk(sB * Rmax, 0), hc(sB * Rmax, 0), hbi(sB * Rmax, 0), hbj(sB * Rmax, 0);
-  std::vector<double> hcoef(sB * Rmax * k, 0.0), hrhs(sB * Rmax, 0.0), hx(sB * w.Lmax * n, 0.0);
+  std::vector<int> hR(B), hk(sN * Rmax, 0), hc(sN * Rmax, 0), hbi(sN * Rmax, 0), hbj(sN * Rmax, 0);
+  std::vector<double> hcoef(sN * Rmax * k, 0.0), hrhs(sN * Rmax, 0.0), hx(sN * w.Lmax * n, 0.0);
   cutbase = 0;
   for (int b = 0; b < B; ++b) {
     hR[b] = (int)rk[b].size();
@@ -492,7 +517,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       }
     }
   }
-  HIPCHK(hipMemsetAsync(w.sweeps, 0, sizeof(int) * B, h->stream));
+  HIPCHK(hipMemsetAsync(w.sweeps, 0, sizeof(int) * S, h->stream));
   HIPCHK(hipMemsetAsync(w.stamps, 0, 32 * 8, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->staged = true;
@@ -524,53 +549,93 @@ int omc_relax_solve(omc_instance* h) {
   h->ev_used = 0; h->ev_class.clear();
   auto t0 = std::chrono::steady_clock::now();
   hipStream_t s = h->stream;
-  const int B = w.B;
-  TIMED(OMC_KERNEL_SETUP, B, omc_launch_setup(&w, s));
-  std::vector<int> done(B, 0);
-  int nactive = B;
+  const int S = w.B, Btot = w.Btot;
+  // slot bookkeeping on the host: node of each slot (-1 = idle), next pending node
+  std::vector<int> node_of(S), flags(3 * (size_t)S), done(S, 0);
+  for (int b = 0; b < S; ++b) node_of[b] = b;
+  int next = S, harvested = 0, nactive = S;
+  auto push_flags = [&](const std::vector<int>& init, const std::vector<int>& fin) -> int {
+    for (int b = 0; b < S; ++b) { flags[b] = node_of[b] < 0 ? 0 : node_of[b]; flags[S + b] = init[b]; flags[2 * (size_t)S + b] = fin[b]; }
+    HIPCHK(hipMemcpyAsync(w.node_of, flags.data(), sizeof(int) * flags.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                  // `flags` is rewritten by the next push
+    return 0;
+  };
+  {
+    std::vector<int> init(S, 1), fin(S, 0);
+    int rc = push_flags(init, fin); if (rc) return rc;
+  }
+  TIMED(OMC_KERNEL_SETUP, S, omc_launch_setup(&w, s));
   int it = 0;
   const int check = std::max(1, P.check_every);
   bool timed_out = false;
-  while (it < P.max_iters && nactive > 0) {
+  h->total_sweeps = 0;
+  while (nactive > 0) {
     ++it;
     TIMED(OMC_KERNEL_COLPROX, (int64_t)nactive * w.m, omc_launch_colprox(&w, 0, s));
     if (h->ws_lpp) TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone_ws(&w, h->ws_lpp, h->ws_use_lds, h->ws_lds, s));
     else TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone(&w, CONE_CLIP01, h->cone_use_lds, h->cone_lds, s));
     TIMED(OMC_KERNEL_SMALL, nactive, omc_launch_small(&w, SMALL_PROJ, h->small_use_lds, h->small_lds, s));
     TIMED(OMC_KERNEL_GLOBAL, nactive, omc_launch_global(&w, h->glob_use_lds, h->glob_lds, s));
-    const bool last = (it == P.max_iters);
-    if (it % check == 0 || last) {
-      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      timed_out = el > P.time_limit;
-      TIMED(OMC_KERNEL_CHECK, nactive, {
-        omc_launch_check_zero(&w, s);
-        omc_launch_colprox(&w, 1, s);
-        omc_launch_check_build(&w, s);
-        omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
-        omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : (last ? OMC_ST_SLOW : 0), s);
-        if (w.bump_max > 0) omc_launch_rho_rescale(&w, s);
+    if (it % check != 0) continue;
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    timed_out = el > P.time_limit;
+    TIMED(OMC_KERNEL_CHECK, nactive, {
+      omc_launch_check_zero(&w, s);
+      omc_launch_colprox(&w, 1, s);
+      omc_launch_check_build(&w, s);
+      omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
+      omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, s);      // per-slot iteration cap is applied on the device
+      if (w.bump_max > 0) omc_launch_rho_rescale(&w, s);
+    });
+    HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * S, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // harvest finished slots, hand them the next pending nodes
+    std::vector<int> init(S, 0), fin(S, 0);
+    int nfin = 0;
+    for (int b = 0; b < S; ++b) if (node_of[b] >= 0 && done[b]) { fin[b] = 1; ++nfin; }
+    if (nfin) {
+      int rc = push_flags(init, fin); if (rc) return rc;
+      TIMED(OMC_KERNEL_CHECK, nfin, {
+        omc_launch_small(&w, SMALL_RECOVER, h->small_use_lds, h->small_lds, s);   // a U with U U' <= Y and the same Q'U
+        omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, s);           // separation vector (OMC.jl:2466-2477)
+        omc_launch_harvest(&w, s);
       });
-      HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+      harvested += nfin;
+      int ninit = 0;
+      for (int b = 0; b < S; ++b) {
+        if (!fin[b]) continue;
+        fin[b] = 0;
+        if (next < Btot && !timed_out) { node_of[b] = next++; init[b] = 1; ++ninit; }
+        else node_of[b] = -1;
+      }
+      rc = push_flags(init, fin); if (rc) return rc;
+      if (ninit) TIMED(OMC_KERNEL_SETUP, ninit, omc_launch_setup(&w, s));
+    }
+    nactive = 0;
+    for (int b = 0; b < S; ++b) nactive += node_of[b] >= 0 ? 1 : 0;
+    if (timed_out && next < Btot) {
+      // nodes that never got a slot: report TIME_LIMIT without values
+      std::vector<int> st(Btot - next, OMC_ST_TIME), itz(Btot - next, 0);
+      std::vector<double> inf(Btot - next, 1e300), ninf(Btot - next, -1e300);
+      HIPCHK(hipMemcpyAsync(w.ostatus + next, st.data(), sizeof(int) * st.size(), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(w.oiters + next, itz.data(), sizeof(int) * itz.size(), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(w.oobj + next, inf.data(), 8 * inf.size(), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(w.olb + next, ninf.data(), 8 * ninf.size(), hipMemcpyHostToDevice, s));
       HIPCHK(hipStreamSynchronize(s));
-      nactive = 0;
-      for (int b = 0; b < B; ++b) nactive += done[b] ? 0 : 1;
-      if (timed_out) break;
+      next = Btot;
     }
   }
-  // separation vector of every node on its final (Y, U)  (OMC.jl:2466-2477)
-  TIMED(OMC_KERNEL_CHECK, B, {
-    omc_launch_small(&w, SMALL_RECOVER, h->small_use_lds, h->small_lds, s);   // a U with U U' <= Y and the same Q'U
-    omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, s);
-  });
   {
-    std::vector<int> sw(B);
-    HIPCHK(hipMemcpyAsync(sw.data(), w.sweeps, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    std::vector<int> sw(S);
+    HIPCHK(hipMemcpyAsync(sw.data(), w.sweeps, sizeof(int) * S, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    h->total_sweeps = 0; for (int v : sw) h->total_sweeps += v;
+    for (int v : sw) h->total_sweeps += v;
   }
   HIPCHK(hipGetLastError());
   finish_events(h);
   h->last_solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  h->last_iters_total = it;
+  (void)harvested;
   return 0;
 }
 
@@ -579,16 +644,16 @@ int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int*
   if (!h || !h->staged) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch: nothing staged");
   HIPCHK(hipSetDevice(h->device));
   const OmcWS& w = h->ws;
-  const size_t B = w.B, n = w.n, m = w.m, k = w.k;
+  const size_t B = w.Btot, n = w.n, m = w.m, k = w.k;
   hipStream_t s = h->stream;
-  if (objective) HIPCHK(hipMemcpyAsync(objective, w.objout, 8 * B, hipMemcpyDeviceToHost, s));
-  if (dual_bound) HIPCHK(hipMemcpyAsync(dual_bound, w.lb, 8 * B, hipMemcpyDeviceToHost, s));
-  if (status) HIPCHK(hipMemcpyAsync(status, w.status, 4 * B, hipMemcpyDeviceToHost, s));
-  if (iters) HIPCHK(hipMemcpyAsync(iters, w.iters, 4 * B, hipMemcpyDeviceToHost, s));
-  if (Y) HIPCHK(hipMemcpyAsync(Y, w.Y, 8 * B * n * n, hipMemcpyDeviceToHost, s));
-  if (U) HIPCHK(hipMemcpyAsync(U, w.U, 8 * B * n * k, hipMemcpyDeviceToHost, s));
-  if (lambda_min) HIPCHK(hipMemcpyAsync(lambda_min, w.lmin, 8 * 2 * B, hipMemcpyDeviceToHost, s));
-  if (breakpoint_x) HIPCHK(hipMemcpyAsync(breakpoint_x, w.bx, 8 * B * n, hipMemcpyDeviceToHost, s));
+  if (objective) HIPCHK(hipMemcpyAsync(objective, w.oobj, 8 * B, hipMemcpyDeviceToHost, s));
+  if (dual_bound) HIPCHK(hipMemcpyAsync(dual_bound, w.olb, 8 * B, hipMemcpyDeviceToHost, s));
+  if (status) HIPCHK(hipMemcpyAsync(status, w.ostatus, 4 * B, hipMemcpyDeviceToHost, s));
+  if (iters) HIPCHK(hipMemcpyAsync(iters, w.oiters, 4 * B, hipMemcpyDeviceToHost, s));
+  if (Y) HIPCHK(hipMemcpyAsync(Y, w.oY, 8 * B * n * n, hipMemcpyDeviceToHost, s));
+  if (U) HIPCHK(hipMemcpyAsync(U, w.oU, 8 * B * n * k, hipMemcpyDeviceToHost, s));
+  if (lambda_min) HIPCHK(hipMemcpyAsync(lambda_min, w.olmin, 8 * 2 * B, hipMemcpyDeviceToHost, s));
+  if (breakpoint_x) HIPCHK(hipMemcpyAsync(breakpoint_x, w.obx, 8 * B * n, hipMemcpyDeviceToHost, s));
   if (X || Theta) {
     int r_ = h->bXout.ensure(8 * B * n * m); if (r_) return r_;
     omc_launch_make_X(&w, h->bXout.as<double>(), s);
@@ -638,7 +703,7 @@ int omc_separation_batch(omc_instance* h, int B, int breakpoints, const double* 
     return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts breakpoints (OMC.jl:2440-2446)");
   // stage an empty batch to get a workspace of the right size, then overwrite (Y, U)
   std::vector<int> L(B, 0);
-  omc_relax_params P = h->params; P.breakpoints = breakpoints;
+  omc_relax_params P = h->params; P.breakpoints = breakpoints; P.slots = B;   // identity slot map: the state arrays are addressed by node
   int rc = omc_relax_stage(h, B, &P, OMC_CUT_LINEAR, L.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
   if (rc) return rc;
   const OmcWS& w = h->ws;
@@ -662,7 +727,8 @@ int omc_separation_batch(omc_instance* h, int B, int breakpoints, const double* 
 int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded) {
   if (!h || !Y || !U_rounded) return fail(OMC_ERR_ARGUMENT, "NULL argument");
   std::vector<int> L(B, 0);
-  int rc = omc_relax_stage(h, B, &h->params, OMC_CUT_LINEAR, L.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+  omc_relax_params P = h->params; P.slots = B;
+  int rc = omc_relax_stage(h, B, &P, OMC_CUT_LINEAR, L.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
   if (rc) return rc;
   const OmcWS& w = h->ws;
   const size_t n = h->n, k = h->k;

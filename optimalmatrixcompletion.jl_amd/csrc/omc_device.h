@@ -26,7 +26,12 @@
 
 struct OmcWS {
   // sizes
-  int B, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16, max_sweeps;
+  // B = number of SLOTS (state arrays, grid size); Btot = number of nodes of the staged batch (descriptor and output arrays).
+  // node_of[b] = node currently relaxed in slot b.
+  int B, Btot, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16, max_sweeps, max_iters;
+  int *node_of, *init, *fin;   // B
+  const double* rho_node;      // Btot: initial penalty of each node
+  double *oY, *oU, *oalphaX, *obx, *oobj, *olb, *olmin, *orho; int *ostatus, *oiters;   // per-node outputs
   // parameters
   double gamma, rho, rho_f_ratio, relax, eps_gap, eps_feas, sumA2, jacobi_tau;   // rho: batch default (rho_b holds the per-node value)
   double* rho_b;          // B: ADMM penalty of node b (bumped on the device)
@@ -93,6 +98,7 @@ void omc_launch_check_zero(const OmcWS* w, hipStream_t s);
 void omc_launch_check_build(const OmcWS* w, hipStream_t s);
 void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s);
+void omc_launch_harvest(const OmcWS* w, hipStream_t s);
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s);
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s);
 void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,

@@ -32,20 +32,22 @@
 //   rows of node b:  <CY_r, Y> + <CU_r, U> <= rhs_r ;  CY_r = I (trace) | x x' (cut) | 0 ;  CU_r = x (x) coef_r
 //   (bound / cut rows) or a single entry (box rows).   G1_rr' = <CY_r, CY_r'>_{1/wY1} + <CU_r, CU_r'> / 2
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rowU_entry(const OmcWS& w, int b, int r, int i, int j) {
-  // coefficient of U[i][j] in row r of node b
-  const int kind = w.rkind[(size_t)b * w.Rmax + r];
+__device__ __forceinline__ double rowU_entry(const OmcWS& w, int nb, int r, int i, int j) {
+  // coefficient of U[i][j] in row r of node nb (descriptor index, not the slot)
+  const int kind = w.rkind[(size_t)nb * w.Rmax + r];
   if (kind == ROW_TRACE) return 0.0;
   if (kind == ROW_BOX) {
-    return (w.rbi[(size_t)b * w.Rmax + r] == i && w.rbj[(size_t)b * w.Rmax + r] == j)
-               ? w.rcoef[((size_t)b * w.Rmax + r) * w.k]
+    return (w.rbi[(size_t)nb * w.Rmax + r] == i && w.rbj[(size_t)nb * w.Rmax + r] == j)
+               ? w.rcoef[((size_t)nb * w.Rmax + r) * w.k]
                : 0.0;
   }
-  const int l = w.rcut[(size_t)b * w.Rmax + r];
-  return w.cutx[((size_t)b * w.Lmax + l) * w.n + i] * w.rcoef[((size_t)b * w.Rmax + r) * w.k + j];
+  const int l = w.rcut[(size_t)nb * w.Rmax + r];
+  return w.cutx[((size_t)nb * w.Lmax + l) * w.n + i] * w.rcoef[((size_t)nb * w.Rmax + r) * w.k + j];
 }
 
 __global__ void k_setup(OmcWS w) {
+  if (!w.init[blockIdx.x]) return;                 // only slots that received a new node
+  const int nb = w.node_of[blockIdx.x];
   const int b = blockIdx.x, n = w.n, k = w.k, tid = threadIdx.x, T = blockDim.x, rm = w.rmax;
   __shared__ double red[32];
   double* Y = w.Y + (size_t)b * n * n;
@@ -77,23 +79,24 @@ __global__ void k_setup(OmcWS w) {
   }
   for (int e = tid; e < w.nnz; e += T) w.alpha[(size_t)b * w.nnz + e] = 0.0;
   for (int e = tid; e < w.m; e += T) w.sval[(size_t)b * w.m + e] = -1.0;
-  const int R = w.R[b];
+  const int R = w.R[nb];
   for (int e = tid; e < w.Rmax; e += T) w.lam[(size_t)b * w.Rmax + e] = 0.0;
   if (tid == 0) {
+    w.init[b] = 0; w.rho_b[b] = w.rho_node[nb];
     w.done[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0; w.nbump[b] = 0; w.lastbump[b] = 0; w.bfac[b] = 1.0;
     w.obj[b] = 1e300; w.objout[b] = 1e300; w.objprev[b] = 1e300; w.lbprev[b] = -1e300; w.lb[b] = -1e300; w.rp[b] = 1e300; w.rd[b] = 1e300;
   }
   // Gram matrix for rho = 1
   double* G = w.G + (size_t)b * w.Rmax * w.Rmax;
   for (int r = 0; r < R; ++r) {
-    const int kr = w.rkind[(size_t)b * w.Rmax + r];
+    const int kr = w.rkind[(size_t)nb * w.Rmax + r];
     for (int s = r; s < R; ++s) {
-      const int ks = w.rkind[(size_t)b * w.Rmax + s];
+      const int ks = w.rkind[(size_t)nb * w.Rmax + s];
       double acc = 0.0;
       const bool yr = (kr == ROW_TRACE || kr == ROW_CUT), ys = (ks == ROW_TRACE || ks == ROW_CUT);
       if (yr && ys) {
-        const double* xr = (kr == ROW_CUT) ? w.cutx + ((size_t)b * w.Lmax + w.rcut[(size_t)b * w.Rmax + r]) * n : nullptr;
-        const double* xs = (ks == ROW_CUT) ? w.cutx + ((size_t)b * w.Lmax + w.rcut[(size_t)b * w.Rmax + s]) * n : nullptr;
+        const double* xr = (kr == ROW_CUT) ? w.cutx + ((size_t)nb * w.Lmax + w.rcut[(size_t)nb * w.Rmax + r]) * n : nullptr;
+        const double* xs = (ks == ROW_CUT) ? w.cutx + ((size_t)nb * w.Lmax + w.rcut[(size_t)nb * w.Rmax + s]) * n : nullptr;
         if (!xr && !xs) {
           for (int i = tid; i < n; i += T) acc += 1.0 / w.wY1[(size_t)i * n + i];
         } else if (!xr || !xs) {
@@ -109,8 +112,8 @@ __global__ void k_setup(OmcWS w) {
       if (kr != ROW_TRACE && ks != ROW_TRACE) {
         for (int e = tid; e < n * k; e += T) {
           int i = e % n, j = e / n;
-          double a = rowU_entry(w, b, r, i, j);
-          if (a != 0.0) acc += a * rowU_entry(w, b, s, i, j) * 0.5;
+          double a = rowU_entry(w, nb, r, i, j);
+          if (a != 0.0) acc += a * rowU_entry(w, nb, s, i, j) * 0.5;
         }
       }
       double tot = block_sum(acc, red);
@@ -487,6 +490,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
   __shared__ double s_base;
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] && mode != CONE_SEP && mode != CONE_TOPK) return;
+  if ((mode == CONE_SEP || mode == CONE_TOPK) && !w.fin[b]) return;
   const int n = w.n, k = w.k;
   const int N = n;
   const int Np = (N + 1) & ~1, ld = Np | 1;
@@ -812,8 +816,10 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   __shared__ double s_base;
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] && mode == SMALL_PROJ) return;
+  if (mode == SMALL_RECOVER && !w.fin[b]) return;   // recovery runs once, when the slot's node is harvested
+  const int nb = w.node_of[b];
   const int n = w.n, k = w.k, rm = w.rmax;
-  const int r = w.rr[b];
+  const int r = w.rr[nb];
   const int N3 = (mode == SMALL_PROJ) ? r + k : r;
   const int Np = (N3 + 1) & ~1, ld = Np | 1;
   auto base = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.small_scratch + (size_t)b * w.small_scratch_stride; }();
@@ -826,7 +832,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   double* wgt = ev + Npm;
   int* sel = (int*)(wgt + Npm);
   double* Cc = (double*)(sel + Npm + (Npm & 1));  // r x k coefficients (recover)
-  const double* Q = w.Qb + (size_t)b * n * rm;
+  const double* Q = w.Qb + (size_t)nb * n * rm;
   const double* Y = w.Y + (size_t)b * n * n;
   const double* D3 = w.D3 + (size_t)b * n * n;
   const double* Vt = w.Vt + (size_t)b * rm * k;
@@ -960,8 +966,9 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   __shared__ int s_pl[NNQP_PMAX];
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
+  const int nb = w.node_of[b];
   const int n = w.n, k = w.k, m = w.m, rm = w.rmax;
-  const int R = w.R[b], r = w.rr[b];
+  const int R = w.R[nb], r = w.rr[nb];
   auto tY = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.glob_scratch + (size_t)b * w.glob_scratch_stride; }();
   double* tU = tY + (size_t)n * m;       // n*k   (tU, then the full-space U correction); the first region is n*m >= n*n doubles
   double* tV = tU + (size_t)n * k;       // rm*k
@@ -978,7 +985,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const double* W1 = w.W1 + (size_t)b * n * n;
   const double* E3 = w.E3 + (size_t)b * n * n;
   const double* W3V = w.W3V + (size_t)b * rm * k;
-  const double* Q = w.Qb + (size_t)b * n * rm;
+  const double* Q = w.Qb + (size_t)nb * n * rm;
   const double rho = w.rho_b[b], rho_f = rho * w.rho_f_ratio, rx = w.relax, g = w.gamma;
   STAMP_BEGIN();
   // 1. gamma/2 * Lambda Lambda', output-stationary and deterministic.  LDS path: the dense column-major copy of Lambda
@@ -1049,24 +1056,24 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   __syncthreads();
   STAMP(9);
   // 3. c = A t - b
-  const double* cutx = w.cutx + (size_t)b * w.Lmax * n;
+  const double* cutx = w.cutx + (size_t)nb * w.Lmax * n;
   for (int rr = 0; rr < R; ++rr) {
-    const int kind = w.rkind[(size_t)b * w.Rmax + rr];
+    const int kind = w.rkind[(size_t)nb * w.Rmax + rr];
     double acc = 0.0;
     if (kind == ROW_TRACE) {
       for (int i = tid; i < n; i += T) acc += tY[(size_t)i * n + i];
     } else if (kind == ROW_BOX) {
-      if (tid == 0) acc = w.rcoef[((size_t)b * w.Rmax + rr) * k] * tU[(size_t)w.rbj[(size_t)b * w.Rmax + rr] * n + w.rbi[(size_t)b * w.Rmax + rr]];
+      if (tid == 0) acc = w.rcoef[((size_t)nb * w.Rmax + rr) * k] * tU[(size_t)w.rbj[(size_t)nb * w.Rmax + rr] * n + w.rbi[(size_t)nb * w.Rmax + rr]];
     } else {
-      const double* x = cutx + (size_t)w.rcut[(size_t)b * w.Rmax + rr] * n;
-      const double* cf = w.rcoef + ((size_t)b * w.Rmax + rr) * k;
+      const double* x = cutx + (size_t)w.rcut[(size_t)nb * w.Rmax + rr] * n;
+      const double* cf = w.rcoef + ((size_t)nb * w.Rmax + rr) * k;
       if (kind == ROW_CUT) {
         for (int e = tid; e < n * n; e += T) { int i = e % n, j = e / n; acc += x[i] * x[j] * tY[e]; }
       }
       for (int e = tid; e < n * k; e += T) { int i = e % n, j = e / n; if (cf[j] != 0.0) acc += cf[j] * x[i] * tU[e]; }
     }
     double tot = block_sum(acc, red);
-    if (tid == 0) cvec[rr] = tot - w.rrhs[(size_t)b * w.Rmax + rr];
+    if (tid == 0) cvec[rr] = tot - w.rrhs[(size_t)nb * w.Rmax + rr];
   }
   __syncthreads();
   STAMP(10);
@@ -1079,7 +1086,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   for (int e = tid; e < n * k; e += T) {
     int i = e % n, j = e / n;
     double corr = 0.0;
-    for (int rr = 0; rr < R; ++rr) { double mv = mu[rr]; if (mv != 0.0) corr += mv * rowU_entry(w, b, rr, i, j); }
+    for (int rr = 0; rr < R; ++rr) { double mv = mu[rr]; if (mv != 0.0) corr += mv * rowU_entry(w, nb, rr, i, j); }
     tU[e] = 0.5 * corr;
   }
   __syncthreads();
@@ -1119,9 +1126,9 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     for (int rr = 0; rr < R; ++rr) {
       const double mv = mu[rr];
       if (mv == 0.0) continue;
-      const int kind = w.rkind[(size_t)b * w.Rmax + rr];
+      const int kind = w.rkind[(size_t)nb * w.Rmax + rr];
       if (kind == ROW_TRACE) tm += mv;
-      else if (kind == ROW_CUT && c2 < NNQP_PMAX) { s_act[c2] = w.rcut[(size_t)b * w.Rmax + rr]; s_mu[c2] = mv; ++c2; }
+      else if (kind == ROW_CUT && c2 < NNQP_PMAX) { s_act[c2] = w.rcut[(size_t)nb * w.Rmax + rr]; s_mu[c2] = mv; ++c2; }
     }
     s_nact = c2; s_trace_mu = tm;
   }
@@ -1165,12 +1172,13 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
   extern __shared__ double smem[];   // n*k doubles: cU
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
-  const int n = w.n, k = w.k, m = w.m, R = w.R[b], rm = w.rmax, r = w.rr[b];
+  const int nb = w.node_of[b];
+  const int n = w.n, k = w.k, m = w.m, R = w.R[nb], rm = w.rmax, r = w.rr[nb];
   double* M = w.Mchk + (size_t)b * n * n;
   const double* E3 = w.E3 + (size_t)b * n * n;
   const double* lam = w.lam + (size_t)b * w.Rmax;
-  const double* cutx = w.cutx + (size_t)b * w.Lmax * n;
-  const double* Q = w.Qb + (size_t)b * n * rm;
+  const double* cutx = w.cutx + (size_t)nb * w.Lmax * n;
+  const double* Q = w.Qb + (size_t)nb * n * rm;
   const double rho = w.rho_b[b], g = w.gamma;
   double* cU = w.chk_scratch + (size_t)b * n * k;
   for (int e = tid; e < n * n; e += T) {
@@ -1178,8 +1186,8 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
     double v = -rho * E3[e];
     for (int rr = 0; rr < R; ++rr) {
       double lv = lam[rr];
-      if (lv != 0.0 && w.rkind[(size_t)b * w.Rmax + rr] == ROW_CUT) {
-        const double* x = cutx + (size_t)w.rcut[(size_t)b * w.Rmax + rr] * n;
+      if (lv != 0.0 && w.rkind[(size_t)nb * w.Rmax + rr] == ROW_CUT) {
+        const double* x = cutx + (size_t)w.rcut[(size_t)nb * w.Rmax + rr] * n;
         v += lv * x[i] * x[j];
       }
     }
@@ -1188,7 +1196,7 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
   for (int e = tid; e < n * k; e += T) {
     int i = e % n, j = e / n;
     double cu = 0.0;
-    for (int rr = 0; rr < R; ++rr) { double lv = lam[rr]; if (lv != 0.0) cu += lv * rowU_entry(w, b, rr, i, j); }
+    for (int rr = 0; rr < R; ++rr) { double lv = lam[rr]; if (lv != 0.0) cu += lv * rowU_entry(w, nb, rr, i, j); }
     cU[e] = cu;
   }
   __syncthreads();
@@ -1214,7 +1222,7 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
   if (tid == 0) {
     double cst = 0.0;
     for (int rr = 0; rr < R; ++rr)
-      if (w.rkind[(size_t)b * w.Rmax + rr] != ROW_TRACE) cst -= lam[rr] * w.rrhs[(size_t)b * w.Rmax + rr];
+      if (w.rkind[(size_t)nb * w.Rmax + rr] != ROW_TRACE) cst -= lam[rr] * w.rrhs[(size_t)nb * w.Rmax + rr];
     for (int j = 0; j < k; ++j) cst -= rho * w.Q3T[(size_t)b * k * k + (size_t)j * k + j];
     w.cpen[b] = pen; w.cst[b] = cst;
   }
@@ -1241,6 +1249,7 @@ __global__ void k_check_final(OmcWS w, int last) {
     w.done[b] = 1; w.status[b] = okgap ? OMC_ST_OPTIMAL : OMC_ST_SLOW; return;
   }
   if (last) { w.done[b] = 1; w.status[b] = last; return; }
+  if (w.iters[b] >= w.max_iters) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }
   // penalty bump: crawling nodes with active cuts show rp >> rd
   w.bfac[b] = 1.0;
   if (w.bump_max > 0 && w.iters[b] >= w.bump_after && w.nbump[b] < w.bump_max && w.iters[b] - w.lastbump[b] >= w.bump_gap &&
@@ -1273,6 +1282,23 @@ __global__ void __launch_bounds__(256) k_rho_rescale(OmcWS w) {
   if (tid == 0) { w.fro2[b] = fr2; w.bfac[b] = 1.0; }
 }
 
+// copy the results of the slots flagged `fin` to the per-node output arrays (continuous batching: a slot is re-used)
+__global__ void __launch_bounds__(256) k_harvest(OmcWS w) {
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (!w.fin[b]) return;
+  const int nb = w.node_of[b];
+  const int n = w.n, k = w.k;
+  for (int e = tid; e < n * n; e += T) w.oY[(size_t)nb * n * n + e] = w.Y[(size_t)b * n * n + e];
+  for (int e = tid; e < n * k; e += T) w.oU[(size_t)nb * n * k + e] = w.U[(size_t)b * n * k + e];
+  for (int e = tid; e < w.nnz; e += T) w.oalphaX[(size_t)nb * w.nnz + e] = w.alphaX[(size_t)b * w.nnz + e];
+  for (int e = tid; e < n; e += T) w.obx[(size_t)nb * n + e] = w.bx[(size_t)b * n + e];
+  if (tid == 0) {
+    w.oobj[nb] = w.objout[b]; w.olb[nb] = w.lb[b]; w.ostatus[nb] = w.status[b]; w.oiters[nb] = w.iters[b];
+    w.olmin[2 * nb] = w.lmin[2 * b]; w.olmin[2 * nb + 1] = w.lmin[2 * b + 1];
+    w.orho[nb] = w.rho_b[b];
+  }
+}
+
 __global__ void k_zero_check(OmcWS w) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= w.B || w.done[b]) return;
@@ -1284,8 +1310,8 @@ __global__ void k_zero_check(OmcWS w) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_make_X(OmcWS w, double* X) {
   const int b = blockIdx.y, n = w.n, m = w.m;
-  const double* Y = w.Y + (size_t)b * n * n;
-  const double* al = w.alphaX + (size_t)b * w.nnz;
+  const double* Y = w.oY + (size_t)b * n * n;
+  const double* al = w.oalphaX + (size_t)b * w.nnz;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * m; e += gridDim.x * blockDim.x) {
     int i = e % n, j = e / n;
     const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
@@ -1296,7 +1322,7 @@ __global__ void k_make_X(OmcWS w, double* X) {
 }
 __global__ void k_make_Theta(OmcWS w, const double* X, double* Th) {
   const int b = blockIdx.y, n = w.n, m = w.m;
-  const double* al = w.alphaX + (size_t)b * w.nnz;
+  const double* al = w.oalphaX + (size_t)b * w.nnz;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m * m; e += gridDim.x * blockDim.x) {
     int i = e % m, j = e / m;  // Theta[i][j] = gamma * sum_p Lx[p,i] X[p,j]
     const int off = w.col_ptr[i], c = w.col_ptr[i + 1] - off;
@@ -1375,9 +1401,10 @@ void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s) {
   hipLaunchKernelGGL(k_check_final, dim3((w->B + 63) / 64), dim3(64), 0, s, *w, last);
 }
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_rho_rescale, dim3(w->B), dim3(256), 0, s, *w); }
-void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s) { hipLaunchKernelGGL(k_make_X, dim3(64, w->B), dim3(256), 0, s, *w, X); }
+void omc_launch_harvest(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_harvest, dim3(w->B), dim3(256), 0, s, *w); }
+void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s) { hipLaunchKernelGGL(k_make_X, dim3(64, w->Btot), dim3(256), 0, s, *w, X); }
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s) {
-  hipLaunchKernelGGL(k_make_Theta, dim3(64, w->B), dim3(256), 0, s, *w, X, Th);
+  hipLaunchKernelGGL(k_make_Theta, dim3(64, w->Btot), dim3(256), 0, s, *w, X, Th);
 }
 void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,
                                double* out, hipStream_t s) {

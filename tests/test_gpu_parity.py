@@ -200,3 +200,22 @@ def test_altmin_and_rounding_match_oracle(have_gpu, omc, orc):
     with pytest.raises(ValueError):
         eng.alternating_minimization([U0], [[]], "cubic")
     eng.close()
+
+
+def test_continuous_batching_slots(have_gpu, omc, orc):
+    """More nodes than slots: a finished slot is harvested and re-used; per-node results must not depend on the slot count."""
+    n, m, k = 20, 24, 1
+    A, mask = orc.make_instance(n, m, k, seed=41, kind="readme")
+    inst = orc.Instance(A, mask, GAMMA, k)
+    nodes = oracle_path(orc, inst, "linear", 5, 16.0, seed=9)
+    nodes = nodes + nodes[1:4]                                              # 9 nodes
+    eng = omc.Engine(A, mask, GAMMA, k)
+    ref = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=omc.default_params(rho_scale=16.0))
+    for slots in (1, 2, 4):
+        out = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=omc.default_params(rho_scale=16.0, slots=slots))
+        for a, b in zip(out, ref):
+            assert a["status_code"] == b["status_code"] and a["iters"] == b["iters"]
+            assert a["objective"] == pytest.approx(b["objective"], rel=1e-12) and a["dual_bound"] == pytest.approx(b["dual_bound"], rel=1e-12)
+            assert np.allclose(a["U"], b["U"], atol=1e-12) and np.allclose(a["X"], b["X"], atol=1e-12)
+            assert np.allclose(a["breakpoint_vec"], b["breakpoint_vec"], atol=1e-10)
+    eng.close()
