@@ -452,10 +452,10 @@ class RelaxParams:
     rho_init: float = 0.0        # > 0: start from this penalty (e.g. the parent's final rho)
     bump: int = 1                # 1: multiply rho by bump_factor when the primal residual exceeds bump_ratio x the dual residual
     bump_factor: float = 4.0
-    bump_window: int = 8         # checks between two bumps
-    bump_after: int = 200        # first iteration at which a bump may happen
-    bump_max: int = 3
-    bump_ratio: float = 8.0
+    bump_window: int = 4         # checks between two bumps
+    bump_after: int = 100        # first iteration at which a bump may happen
+    bump_max: int = 6
+    bump_ratio: float = 4.0
 
 
 def _prox_columns(inst, Yx, alpha, svals, rho_f):
