@@ -219,3 +219,51 @@ def test_continuous_batching_slots(have_gpu, omc, orc):
             assert np.allclose(a["U"], b["U"], atol=1e-12) and np.allclose(a["X"], b["X"], atol=1e-12)
             assert np.allclose(a["breakpoint_vec"], b["breakpoint_vec"], atol=1e-10)
     eng.close()
+
+
+def test_dense_columns_and_deep_paths(have_gpu, omc, orc):
+    """Paths that the small cases above do not reach: columns with more than 64 observed rows (vectors no longer fit one
+    lane each: LDS/global-scratch solves), and a deep node (12 cuts: 37 rows, order-14 small cone)."""
+    rng = np.random.default_rng(3)
+    n, m, k = 70, 72, 1
+    A = rng.standard_normal((n, 1)) @ rng.standard_normal((1, m)) + 0.05 * rng.standard_normal((n, m))
+    mask = rng.random((n, m)) < 0.97                                       # c ~ 68 per column
+    inst = orc.Instance(A, mask, GAMMA, k)
+    assert max(len(c) for c in inst.cols) > 64
+    eng = omc.Engine(A, mask, GAMMA, k)
+    g = eng.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=8.0))[0]
+    r = orc.sdp_relaxation(inst, params=orc.RelaxParams(rho_scale=8.0), want_certificate=False)
+    assert g["status_code"] == r["termination_status"] and g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
+    eng.close()
+    # deep path
+    n, m = 20, 24
+    A, mask = orc.make_instance(n, m, 1, seed=51, kind="readme")
+    inst = orc.Instance(A, mask, GAMMA, 1)
+    nodes = oracle_path(orc, inst, "linear", 12, 16.0, seed=2)
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    sel = [nodes[4], nodes[8], nodes[12]]
+    out = eng.matrix_completion_SDP_relaxation(sel, "linear", params=omc.default_params(rho_scale=16.0))
+    for g, c in zip(out, sel):
+        r = orc.sdp_relaxation(inst, c, "linear", params=orc.RelaxParams(rho_scale=16.0), want_certificate=False)
+        assert g["status_code"] == r["termination_status"]
+        if g["status_code"] != 3:
+            assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL) and g["iters"] == r["iters"]
+    eng.close()
+
+
+def test_large_order_uses_l2_resident_path(have_gpu, omc, orc):
+    """n = 150: G of the cone kernel (150 x 162 x 8 B) and the target of k_global do not fit the LDS budget -> L2-resident
+    variants of the same kernels.  Oracle comparison on the root (the oracle needs ~1 min here)."""
+    n, m, k = 150, 150, 1
+    A, mask = orc.make_instance(n, m, k, seed=61, kind="lowrank", n_indices=int(0.15 * n * m))
+    eng = omc.Engine(A, mask, GAMMA, k)
+    P = omc.default_params(rho_scale=4.0, max_iters=400)
+    g = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P)[0]
+    info = eng.solver_info()
+    assert not info["cone_lds"] and not info["global_lds"]
+    inst = orc.Instance(A, mask, GAMMA, k)
+    r = orc.sdp_relaxation(inst, params=orc.RelaxParams(rho_scale=4.0, max_iters=400), want_certificate=False)
+    assert g["iters"] == r["iters"] and g["status_code"] == r["termination_status"]
+    assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
+    assert g["dual_bound"] == pytest.approx(r["dual_bound"], rel=1e-5)
+    eng.close()
