@@ -163,6 +163,9 @@ int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded
 int omc_last_solver_info(omc_instance* h, double* info);
 /* diagnostic builds (-DOMC_STAMPS) only: accumulated s_memtime ticks per kernel phase of node 0; zeros otherwise */
 int omc_debug_stamps(omc_instance* h, double* out32);
+/* diagnostic builds only: per-slot counters, out[c * slots + b]: c = 0 colprox wave cycles, 1 factorizations, 2 cone cycles,
+ * 3 cone calls, 4 global cycles, 5 small cycles (zeros otherwise) */
+int omc_debug_diag(omc_instance* h, double* out);
 /* last primal / dual ADMM residuals of every node of the staged batch (diagnostics) */
 int omc_debug_residuals(omc_instance* h, double* rp, double* rd);
 int omc_last_kernel_stats(omc_instance* h, int64_t* launches /*NCLASS*/, double* ms /*NCLASS*/,

@@ -388,7 +388,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   ENS(h->bdS, sB * rmax * rmax * 8);
   ENS(h->bsm, sB * ((size_t)4 * rmax * k + 3 * k * k) * 8);
   ENS(h->balpha, sB * h->nnz * 8); ENS(h->balphaX, sB * h->nnz * 8); ENS(h->bsval, sB * m * 8);
-  ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8 + 32 * 8);
+  ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8 + (32 + 8 * sB) * 8);
   ENS(h->bG, sB * Rmax * Rmax * 8); ENS(h->blam, sB * Rmax * 8);
   ENS(h->bscal, sB * 16 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 8 * sizeof(int));
   w.np16 = (n + 15) & ~15;
@@ -518,7 +518,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     }
   }
   HIPCHK(hipMemsetAsync(w.sweeps, 0, sizeof(int) * S, h->stream));
-  HIPCHK(hipMemsetAsync(w.stamps, 0, 32 * 8, h->stream));
+  HIPCHK(hipMemsetAsync(w.stamps, 0, (32 + 8 * (size_t)S) * 8, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->staged = true;
   return 0;
@@ -834,6 +834,12 @@ int omc_debug_residuals(omc_instance* h, double* rp, double* rd) {
 int omc_debug_stamps(omc_instance* h, double* out32) {
   if (!h || !out32 || !h->ws.stamps) return fail(OMC_ERR_ARGUMENT, "no stamps");
   HIPCHK(hipMemcpy(out32, h->ws.stamps, 32 * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int omc_debug_diag(omc_instance* h, double* out /* 8 * slots */) {
+  if (!h || !out || !h->ws.stamps) return fail(OMC_ERR_ARGUMENT, "no diagnostics");
+  HIPCHK(hipMemcpy(out, h->ws.stamps + 32, 8 * 8 * (size_t)h->ws.B, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -22,9 +22,22 @@
 #ifdef OMC_STAMPS
 #define STAMP(slot) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { long long t_ = __builtin_amdgcn_s_memtime(); w.stamps[slot] += (double)(t_ - t_prev_); t_prev_ = t_; } } while (0)
 #define STAMP_BEGIN() long long t_prev_ = __builtin_amdgcn_s_memtime()
+// per-slot diagnostics: diag[cls * B + b] += v  (w.stamps + 32)
+#define DIAG_T0() long long t_diag0_ = __builtin_amdgcn_s_memtime()
+#define DIAG_ADD(cls, b, v) atomicAdd(&w.stamps[32 + (size_t)(cls) * w.B + (b)], (double)(v))
+#define DIAG_CYC(cls, b) DIAG_ADD(cls, b, __builtin_amdgcn_s_memtime() - t_diag0_)
+#define WSTAMP_BEGIN() long long tw_prev_ = __builtin_amdgcn_s_memtime()
+#define WSTAMP_BEGIN2() tw_prev_ = __builtin_amdgcn_s_memtime()
+#define WSTAMP(slot) do { if (b == 0 && j == 0 && lane == 0) { long long t_ = __builtin_amdgcn_s_memtime(); w.stamps[slot] += (double)(t_ - tw_prev_); tw_prev_ = t_; } } while (0)
 #else
+#define WSTAMP_BEGIN() do {} while (0)
+#define WSTAMP_BEGIN2() do {} while (0)
+#define WSTAMP(slot) do {} while (0)
 #define STAMP(slot) do {} while (0)
 #define STAMP_BEGIN() do {} while (0)
+#define DIAG_T0() do {} while (0)
+#define DIAG_ADD(cls, b, v) do {} while (0)
+#define DIAG_CYC(cls, b) do {} while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -185,7 +198,9 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
     bool lo_valid = false;       // lo_valid: Cholesky succeeded at lo and phi(lo) >= 0
     double yr = 0.0, zr = 0.0;
     bool have_final = false;
+    int nfact_ = 0; (void)nfact_;
     for (int it = 0; it < 60; ++it) {
+      ++nfact_;
       for (int e = lane; e < c * c; e += WAVE) {
         int p = e / c, q = e - p * c;
         if (q <= p) Lm[TRI(p, q)] = Bm[TRI(p, q)] + ((p == q) ? cp * s : 0.0);
@@ -213,6 +228,7 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
       s = sn;
     }
     if (!have_final) {
+      ++nfact_;
       for (int e = lane; e < c * c; e += WAVE) {
         int p = e / c, q = e - p * c;
         if (q <= p) Lm[TRI(p, q)] = Bm[TRI(p, q)] + ((p == q) ? cp * s : 0.0);
@@ -222,6 +238,7 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
       solve2(yr, zr, false);
     }
     if (lane == 0) w.sval[(size_t)b * w.m + j] = s;
+    if (lane == 0) DIAG_ADD(1, b, nfact_);
     double* lamD = w.lamD + ((size_t)b * w.m + j) * n;      // dense copy (zeros off the support) for the output-stationary Lambda Lambda'
     if (regpath) { if (lane < c) { alpha[lane] = yr; lamD[idx[lane]] = yr; } }
     else for (int p = lane; p < c; p += WAVE) { alpha[p] = vy[p]; lamD[idx[p]] = vy[p]; }
@@ -249,6 +266,134 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
   }
 }
 
+
+// Fast path for c <= 64 (every lane holds one vector entry in a register).  Root-free Cholesky with G = 64/c lanes per row
+// (omc_wave.h), Halley steps on the secular equation (phi'' = 6 cp^2 z'z comes for free with the Newton data) and a
+// second-order Taylor finish  alpha(s + d) = y - cp d z + cp^2 d^2 w  once the step is small (relative third-order term
+// < 1e-15): one factorization per call late in the ADMM run, two early, instead of the three of Newton + confirmation.
+template <class PT>
+__device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int j, int off, int c, int lane, PT base) {
+  const int n = w.n;
+  const int tri = (c * (c + 1)) >> 1;
+  auto Bm = base;
+  auto Lm = Bm + tri;
+  auto vo = Lm + tri;
+  auto pinv = vo + c;
+  auto sidx = (int*)(pinv + c);
+  const int G = WAVE / c, r = lane / G, g = lane - r * G, rb = tri_i(r, 0);
+  const double gm = w.gamma;
+  const double* Y = w.Y + (size_t)b * n * n;
+  const double* Yp = w.Yp + (size_t)b * n * n;
+  double* alpha = ((mode == 0) ? w.alpha : w.alphaX) + (size_t)b * w.nnz + off;
+  WSTAMP_BEGIN();
+  const double a_reg = (lane < c) ? w.col_val[off + lane] : 0.0;
+  if (lane < c) { vo[lane] = (mode == 0) ? alpha[lane] : 0.0; sidx[lane] = w.col_idx[off + lane]; }
+  WAVE_SYNC();
+  const double rho_f = w.rho_b[b] * w.rho_f_ratio;
+  const double coef = (mode == 0) ? gm / (2.0 * rho_f) : 0.0;
+  if (r < c) {
+    const int ir = sidx[r];
+    const double cr = coef * vo[r];
+    auto dst = (mode == 0) ? Bm : Lm;
+    for (int q = g; q <= r; q += G) {
+      const size_t a = (size_t)sidx[q] * n + ir;
+      const double yv = (mode == 0) ? (2.0 * Y[a] - Yp[a]) : Y[a];
+      double v = gm * (yv - cr * vo[q]);
+      if (q == r) v += 1.0;
+      dst[rb + q] = v;
+    }
+  }
+  const int my = (lane < c) ? sidx[lane] : 0;
+  WSTAMP(21);
+  if (mode == 0) {
+    const double cp = gm * gm / (2.0 * rho_f);
+    const double sprev = w.sval[(size_t)b * w.m + j];
+    double s = (sprev > 0.0) ? sprev : 0.0;
+    double lo = 0.0, hi = -1.0;  // hi < 0: unknown
+    bool lo_valid = false;       // the factorization succeeded at lo and phi(lo) >= 0
+    double yr = 0.0;
+    bool fin = false;
+    int nfact_ = 0; (void)nfact_;
+    for (int it = 0; it < 60; ++it) {
+      ++nfact_;
+      WAVE_SYNC();
+      if (r < c) for (int q = g; q <= r; q += G) Lm[rb + q] = Bm[rb + q] + ((q == r) ? cp * s : 0.0);
+      WSTAMP(22);
+      const bool ok_ = wave_ldl(Lm, pinv, c, r, g, G, lane);
+      WSTAMP(23);
+      if (!ok_) {  // s below the positive definite range: move right
+        lo = s; lo_valid = false;
+        s = (hi > 0.0) ? 0.5 * (s + hi) : (2.0 * s + 1.0);
+        continue;
+      }
+      yr = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
+      const double zr = wave_ldl_solve_reg(Lm, pinv, c, yr, lane);
+      WSTAMP(24);
+      const double yy = wave_sum(yr * yr), yz = wave_sum(yr * zr), zz = wave_sum(zr * zr);
+      const double ph = yy - s, dph = -2.0 * cp * yz - 1.0, ddph = 6.0 * cp * cp * zz;
+      if (ph >= 0.0) { lo = s; lo_valid = true; } else { hi = s; }
+      const double den = 2.0 * dph * dph - ph * ddph;
+      double sn = s + ((den > dph * dph) ? (-2.0 * ph * dph / den) : (-ph / dph));
+      bool guarded = false;
+      if (!(sn > lo) && !lo_valid) { sn = 0.5 * (lo + s); guarded = true; }
+      if (sn < lo) { sn = lo; guarded = true; }
+      if (hi > 0.0 && sn > hi) { sn = 0.5 * (lo + hi); guarded = true; }
+      const double d = sn - s;
+      if (fabs(d) <= 1e-13 * fmax(1.0, fabs(s))) { fin = true; break; }      // the current solve is the answer
+      if (!guarded && yy > 0.0 && cp * fabs(d) * sqrt(zz / yy) < 1e-5) {
+        const double wr = wave_ldl_solve_reg(Lm, pinv, c, zr, lane);
+        yr = yr - cp * d * (zr - cp * d * wr);
+        s = sn; fin = true;
+        WSTAMP(25);
+#ifdef OMC_STAMPS
+        {  // accuracy audit of the Taylor finish: re-factor at the accepted s and compare (diag 6 = max relative error of
+           // alpha, diag 7 = max |phi(s)| / s)
+          WAVE_SYNC();
+          if (r < c) for (int q = g; q <= r; q += G) Lm[rb + q] = Bm[rb + q] + ((q == r) ? cp * s : 0.0);
+          wave_ldl(Lm, pinv, c, r, g, G, lane);
+          const double ye = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
+          double e1 = fabs(ye - yr), e2 = fabs(ye);
+          for (int o = 32; o > 0; o >>= 1) { e1 = fmax(e1, __shfl_xor(e1, o, WAVE)); e2 = fmax(e2, __shfl_xor(e2, o, WAVE)); }
+          const double phe = fabs(wave_sum(ye * ye) - s) / fmax(s, 1e-300);
+          if (lane == 0) {
+            atomicMax((unsigned long long*)&w.stamps[32 + (size_t)6 * w.B + b], (unsigned long long)__double_as_longlong(e1 / fmax(e2, 1e-300)));
+            atomicMax((unsigned long long*)&w.stamps[32 + (size_t)7 * w.B + b], (unsigned long long)__double_as_longlong(phe));
+          }
+        }
+#endif
+        WSTAMP_BEGIN2();
+        break;
+      }
+      s = sn;
+      WSTAMP(26);
+    }
+    if (!fin) {
+      ++nfact_;
+      WAVE_SYNC();
+      if (r < c) for (int q = g; q <= r; q += G) Lm[rb + q] = Bm[rb + q] + ((q == r) ? cp * s : 0.0);
+      wave_ldl(Lm, pinv, c, r, g, G, lane);
+      yr = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
+    }
+    if (lane == 0) w.sval[(size_t)b * w.m + j] = s;
+    if (lane == 0) DIAG_ADD(1, b, nfact_);
+    double* lamD = w.lamD + ((size_t)b * w.m + j) * n;      // dense copy (zeros off the support) for the output-stationary Lambda Lambda'
+    if (lane < c) { alpha[lane] = yr; lamD[my] = yr; }
+    WSTAMP(27);
+  } else {
+    if (!wave_ldl(Lm, pinv, c, r, g, G, lane)) {  // Y not PSD enough on this block: report +inf objective contribution
+      if (lane == 0) atomicAdd(&w.obj[b], 1e300);
+      return;
+    }
+    const double yr = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
+    if (lane < c) alpha[lane] = yr;
+    const double aa = wave_sum(a_reg * yr), al2 = wave_sum(yr * yr);
+    if (lane == 0) {
+      atomicAdd(&w.obj[b], 0.5 * aa);
+      atomicAdd(&w.c0[b], aa - 0.5 * al2);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   extern __shared__ double smem[];
   const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
@@ -258,9 +403,11 @@ __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   if (w.done[b]) return;
   const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
   if (c == 0) return;
+  DIAG_T0();
   // two inlined copies so that the LDS copy compiles to ds_read/ds_write (not flat) instructions
-  if (c <= w.cp_lds_c) colprox_body(w, mode, b, j, off, c, lane, smem + (size_t)wave_in_blk * w.cp_lds_doubles);
+  if (c <= w.cp_lds_c) colprox_reg(w, mode, b, j, off, c, lane, smem + (size_t)wave_in_blk * w.cp_lds_doubles);   // cp_lds_c <= 64
   else colprox_body(w, mode, b, j, off, c, lane, w.cp_scratch + (size_t)gw * w.cp_scratch_stride);
+  if (lane == 0 && mode == 0) DIAG_CYC(0, b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -633,6 +780,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   const double sigma = 1.5 * sqrt(w.fro2[b]) + 1e-300;
   const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
   STAMP_BEGIN();
+  DIAG_T0();
   // ---- 1. G = (M + sigma I) V_prev  (or M + sigma I on the first call) ------------------------------------
   STAMP(5);
   for (int e = tid; e < Np * ld; e += T) Gm[e] = 0.0;
@@ -799,6 +947,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   STAMP(3);
   spectral_rebuild(Gm, ld, N, sel, wgt, s_nsel, s_base, entry2, store);
   STAMP(4);
+  if (tid == 0) { DIAG_CYC(2, b); DIAG_ADD(3, b, 1); }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -837,6 +986,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   const double* D3 = w.D3 + (size_t)b * n * n;
   const double* Vt = w.Vt + (size_t)b * rm * k;
   STAMP_BEGIN();
+  DIAG_T0();
   // T1 = (Y - D3) Q   or  Y Q
   for (int e = tid; e < n * r; e += T) {
     int i = e % n, a = e / n;
@@ -948,6 +1098,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
     E3[(size_t)j * n + i] = acc; E3[(size_t)i * n + j] = acc;
   }
   STAMP(20);
+  if (tid == 0) DIAG_CYC(5, b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -988,6 +1139,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const double* Q = w.Qb + (size_t)nb * n * rm;
   const double rho = w.rho_b[b], rho_f = rho * w.rho_f_ratio, rx = w.relax, g = w.gamma;
   STAMP_BEGIN();
+  DIAG_T0();
   // 1. gamma/2 * Lambda Lambda', output-stationary and deterministic.  LDS path: the dense column-major copy of Lambda
   //    (written by k_colprox, zero where a row is not observed) and the CSR column lists are staged in LDS -- in the
   //    region that holds the target afterwards -- and every thread keeps its <= GL_MAXOUT sums in registers.
@@ -1157,7 +1309,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   rp2 = block_sum(rp2, red);
   rd2 = block_sum(rd2, red);
   fr2 = block_sum(fr2, red);
-  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.fro2[b] = fr2; w.iters[b] += 1; }
+  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.fro2[b] = fr2; w.iters[b] += 1; DIAG_CYC(4, b); }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -105,6 +105,91 @@ __device__ __forceinline__ double wave_chol_solve_reg(LP Lm, DP dinv, int c, dou
   return y;
 }
 
+
+// ---- root-free Cholesky (B = L D L', unit lower L) for c <= 64, packed lower triangle --------------------------------
+// Lane layout: G = 64 / c lanes per row; lane (r, g) owns the entries (r, q) with q = g (mod G).  Step kk needs ONE wave
+// sync: the update  L(r,q) -= L(r,kk) L(q,kk) / piv  reads only column kk, which no lane writes during the step, so neither
+// a square root nor a scaled copy of the column is needed.  On exit Lm(r,q) = L(r,q) d_q below the diagonal and pinv[q] = 1/d_q.
+__device__ __forceinline__ int tri_i(int r, int q) { return (int)(__umul24(r, r + 1) >> 1) + q; }
+// 1 / p for p > 0 in the normal range: v_rcp_f64 + two Newton steps (no scaling / fix-up sequence of the IEEE division)
+__device__ __forceinline__ double fast_rcp(double p) {
+  double x = __builtin_amdgcn_rcp(p);
+  x = fma(fma(-p, x, 1.0), x, x);
+  x = fma(fma(-p, x, 1.0), x, x);
+  return x;
+}
+template <class PT>
+__device__ __forceinline__ bool wave_ldl(PT Lm, PT pinv, int c, int r, int g, int G, int lane) {
+  const int rb = tri_i(r, 0);
+  for (int kk = 0; kk < c; ++kk) {
+    WAVE_SYNC();
+    const double piv = Lm[tri_i(kk, kk)];
+    if (!(piv > 0.0)) return false;
+    const double pi_ = fast_rcp(piv);
+    if (lane == 0) pinv[kk] = pi_;
+    if (r > kk && r < c) {
+      const double ark = Lm[rb + kk] * pi_;
+      // four entries per trip, all loads before the stores, so that the LDS latencies overlap
+      for (int q0 = kk + 1 + g; q0 <= r; q0 += 4 * G) {
+        const int q1 = q0 + G, q2 = q1 + G, q3 = q2 + G;
+        const bool v1 = q1 <= r, v2 = q2 <= r, v3 = q3 <= r;
+        const double a0 = Lm[rb + q0], c0 = Lm[tri_i(q0, kk)];
+        const double a1 = v1 ? Lm[rb + q1] : 0.0, c1 = v1 ? Lm[tri_i(q1, kk)] : 0.0;
+        const double a2 = v2 ? Lm[rb + q2] : 0.0, c2 = v2 ? Lm[tri_i(q2, kk)] : 0.0;
+        const double a3 = v3 ? Lm[rb + q3] : 0.0, c3 = v3 ? Lm[tri_i(q3, kk)] : 0.0;
+        Lm[rb + q0] = fma(-ark, c0, a0);
+        if (v1) Lm[rb + q1] = fma(-ark, c1, a1);
+        if (v2) Lm[rb + q2] = fma(-ark, c2, a2);
+        if (v3) Lm[rb + q3] = fma(-ark, c3, a3);
+      }
+    }
+  }
+  WAVE_SYNC();
+  return true;
+}
+// solve L D L' x = rhs with the vector in registers (lane = entry); column-oriented substitutions, one v_readlane per step,
+// operands of four steps fetched ahead of their use
+template <class PT>
+__device__ __forceinline__ double wave_ldl_solve_reg(PT Lm, PT pinv, int c, double rhs, int lane) {
+  double y = (lane < c) ? rhs : 0.0;
+  const int lb = tri_i(lane, 0);
+  const bool act = lane < c;
+  int q = 0;
+  for (; q + 4 <= c; q += 4) {
+    const double p0 = pinv[q], p1 = pinv[q + 1], p2 = pinv[q + 2], p3 = pinv[q + 3];
+    const double l0 = (act && lane > q) ? Lm[lb + q] : 0.0, l1 = (act && lane > q + 1) ? Lm[lb + q + 1] : 0.0;
+    const double l2 = (act && lane > q + 2) ? Lm[lb + q + 2] : 0.0, l3 = (act && lane > q + 3) ? Lm[lb + q + 3] : 0.0;
+    y = fma(-l0, readlane_d(y, q) * p0, y);
+    y = fma(-l1, readlane_d(y, q + 1) * p1, y);
+    y = fma(-l2, readlane_d(y, q + 2) * p2, y);
+    y = fma(-l3, readlane_d(y, q + 3) * p3, y);
+  }
+  for (; q < c; ++q) {
+    const double t = readlane_d(y, q) * pinv[q];
+    if (act && lane > q) y -= Lm[lb + q] * t;
+  }
+  q = c - 1;
+  for (; q >= 3; q -= 4) {
+    const double p0 = pinv[q], p1 = pinv[q - 1], p2 = pinv[q - 2], p3 = pinv[q - 3];
+    const double l0 = (lane < q) ? Lm[tri_i(q, 0) + lane] : 0.0, l1 = (lane < q - 1) ? Lm[tri_i(q - 1, 0) + lane] : 0.0;
+    const double l2 = (lane < q - 2) ? Lm[tri_i(q - 2, 0) + lane] : 0.0, l3 = (lane < q - 3) ? Lm[tri_i(q - 3, 0) + lane] : 0.0;
+    double xq = readlane_d(y, q) * p0;
+    y = (lane == q) ? xq : fma(-l0, xq, y);
+    xq = readlane_d(y, q - 1) * p1;
+    y = (lane == q - 1) ? xq : fma(-l1, xq, y);
+    xq = readlane_d(y, q - 2) * p2;
+    y = (lane == q - 2) ? xq : fma(-l2, xq, y);
+    xq = readlane_d(y, q - 3) * p3;
+    y = (lane == q - 3) ? xq : fma(-l3, xq, y);
+  }
+  for (; q >= 0; --q) {
+    const double xq = readlane_d(y, q) * pinv[q];
+    if (lane == q) y = xq;
+    else if (lane < q) y -= Lm[tri_i(q, 0) + lane] * xq;
+  }
+  return y;
+}
+
 // solve L L' y = rhs (packed L); y, rhs length c
 __device__ __forceinline__ void wave_chol_solve(const double* Lm, int c, const double* rhs, double* y, int lane) {
   for (int r = 0; r < c; ++r) {
