@@ -151,6 +151,25 @@ int omc_separation_batch(omc_instance* h, int B, int breakpoints, const double* 
 /* ---- rounding glue: svd(M).U[:,1:k] of the symmetric PSD Y (OMC.jl:873) -------------------------------- */
 int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded);
 
+/* ---- Shor minors ------------------------------------------------------------------------------------------
+ * generate_rank1_matrix_completion_Shor_constraints_indexes (OMC.jl:2545-2612): the 2 x 2 minors (i1 < i2, j1 < j2) whose
+ * four cells hold exactly p observed entries, for every p of `num_entries_present` in turn (values outside 0..4
+ * contribute nothing, as in the reference), in the reference's push order; tuples are 1-based Int64, 4 per minor.
+ *   omc_shor_count   : number of minors per list element.
+ *   omc_shor_indexes : *count = total; the tuples are written only when out != NULL and capacity >= total.           */
+int omc_shor_count(omc_instance* h, int n_classes, const int* num_entries_present, int64_t* count_per_class);
+int omc_shor_indexes(omc_instance* h, int n_classes, const int* num_entries_present, int64_t capacity, int64_t* out,
+                     int64_t* count);
+/* generate_violated_Shor_minors (OMC.jl:2614-2640).  X is the reference's Array{Float64,3} of size (k, n, m)
+ * (X[t,i,j] at t + k*(i + n*j)); `existing` = 4*n_existing Int64 (1-based) already imposed minors (setdiff!, OMC.jl:2626).
+ * Output: the min(n_minors, #candidates) minors with the largest score sum_t |X[t,i1,j1] X[t,i2,j2] - X[t,i1,j2] X[t,i2,j1]|,
+ * ordered as Julia orders (score, tuple) pairs with rev = true (ties: larger tuple first).                           */
+int omc_violated_shor_minors(omc_instance* h, const double* X, int n_classes, const int* num_entries_present,
+                             int64_t n_existing, const int64_t* existing, int n_minors, double* scores,
+                             int64_t* minors, int* n_out);
+/* device milliseconds and candidate count of the last omc_shor_indexes / omc_violated_shor_minors call */
+int omc_shor_last_stats(omc_instance* h, double* ms, int64_t* candidates);
+
 /* per-kernel accounting of the last omc_relax_solve: launches and HIP-event milliseconds per kernel class */
 #define OMC_KERNEL_COLPROX 0
 #define OMC_KERNEL_CONE 1

@@ -15,6 +15,7 @@ EXPORTS = [
     "omc_instance_create_bits", "omc_instance_destroy", "omc_relax_batch", "omc_relax_stage", "omc_relax_solve",
     "omc_relax_fetch", "omc_altmin_batch", "omc_evaluate_objective", "omc_separation_batch", "omc_round_Y_batch",
     "omc_last_kernel_stats", "omc_last_solver_info", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag",
+    "omc_shor_count", "omc_shor_indexes", "omc_violated_shor_minors", "omc_shor_last_stats",
 ]
 
 
@@ -66,6 +67,10 @@ def load():
     lib.omc_debug_stamps.argtypes = [vp, vp]
     lib.omc_debug_residuals.argtypes = [vp, vp, vp]
     lib.omc_debug_diag.argtypes = [vp, vp]
+    lib.omc_shor_count.argtypes = [vp, C.c_int, vp, vp]
+    lib.omc_shor_indexes.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp]
+    lib.omc_violated_shor_minors.argtypes = [vp, vp, C.c_int, vp, C.c_int64, vp, C.c_int, vp, vp, vp]
+    lib.omc_shor_last_stats.argtypes = [vp, vp, vp]
     _lib = lib
     return lib
 

@@ -192,6 +192,44 @@ class Engine:
                      solve_time=float(tm[b]), n_iters=int(ni[b]), max_iters=max_iters, objectives=list(obj[b, :ni[b]])) for b in range(B)]
 
     # ---- objective -------------------------------------------------------------------------------------
+    # ---- Shor minors (OMC.jl:2545-2640) ------------------------------------------------------------------------
+    def shor_count(self, num_entries_present_list):
+        cl = np.asarray(list(num_entries_present_list), dtype=np.int32)
+        out = np.zeros(max(len(cl), 1), dtype=np.int64)
+        _lib.check(self._lib.omc_shor_count(self._h, len(cl), _lib.ptr(cl), _lib.ptr(out)))
+        return out[:len(cl)]
+
+    def generate_rank1_matrix_completion_Shor_constraints_indexes(self, num_entries_present_list):
+        """OMC.jl:2545-2612 on the device.  Returns an int64 array (count, 4) of 1-based (i1, i2, j1, j2) in the
+        reference's push order (the instance's `indices` is the mask)."""
+        cl = np.asarray(list(num_entries_present_list), dtype=np.int32)
+        cnt = np.zeros(1, dtype=np.int64)
+        _lib.check(self._lib.omc_shor_indexes(self._h, len(cl), _lib.ptr(cl), 0, None, _lib.ptr(cnt)))
+        out = np.zeros((int(cnt[0]), 4), dtype=np.int64)
+        if cnt[0] > 0:
+            _lib.check(self._lib.omc_shor_indexes(self._h, len(cl), _lib.ptr(cl), int(cnt[0]), _lib.ptr(out), _lib.ptr(cnt)))
+        return out
+
+    def generate_violated_Shor_minors(self, X, num_entries_present_list, Shor_constraints_indexes, n_minors):
+        """OMC.jl:2614-2640 on the device.  X has shape (k, n, m) as in the reference; returns [(score, (i1, i2, j1, j2)), ...]
+        in decreasing (score, tuple) order, at most n_minors of them."""
+        X = np.asarray(X, dtype=np.float64)
+        if X.shape != (self.k, self.n, self.m):
+            raise ValueError("Dimension mismatch.\nInput array X must have size (k, n, m).")
+        Xf = np.asfortranarray(X).ravel(order="F")        # Julia Array{Float64,3} layout
+        cl = np.asarray(list(num_entries_present_list), dtype=np.int32)
+        ex = np.ascontiguousarray(np.asarray(list(Shor_constraints_indexes), dtype=np.int64).reshape(-1, 4))
+        K = int(n_minors)
+        sc = np.zeros(max(K, 1)); mi = np.zeros((max(K, 1), 4), dtype=np.int64); no = np.zeros(1, dtype=np.int32)
+        _lib.check(self._lib.omc_violated_shor_minors(self._h, _lib.ptr(Xf), len(cl), _lib.ptr(cl), len(ex), _lib.ptr(ex) if len(ex) else None,
+                                                      K, _lib.ptr(sc), _lib.ptr(mi), _lib.ptr(no)))
+        return [(float(sc[r]), tuple(int(v) for v in mi[r])) for r in range(int(no[0]))]
+
+    def shor_last_stats(self):
+        ms = np.zeros(1); c = np.zeros(1, dtype=np.int64)
+        _lib.check(self._lib.omc_shor_last_stats(self._h, _lib.ptr(ms), _lib.ptr(c)))
+        return {"ms": float(ms[0]), "candidates": int(c[0])}
+
     def evaluate_objective(self, X):
         X = np.asarray(X, dtype=np.float64)
         single = X.ndim == 2

@@ -21,6 +21,7 @@
 #include "omc.h"
 #include "omc_device.h"
 #include "omc_altmin.h"
+#include "omc_shor.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -71,6 +72,10 @@ struct omc_instance {
   double last_solve_seconds = 0; long long total_sweeps = 0; int last_iters_total = 0;
   std::vector<double> rho_scale_per_node; DevBuf brho, brhon, blamD, bslotint, boY, boU, boal, bobx, boscal, boint;
   int Btot = 0;
+  // Shor minors (a10 / a11): row bitsets and per-pair popcounts, built at the first call
+  DevBuf sbits, scb, scx, scz, soff, stot, sout, shi, slo, sexist, shist, sohi, solo, scnt;
+  bool shor_ready = false; int shor_W = 0; long long shor_pairs = 0;
+  double shor_last_ms = 0; long long shor_last_candidates = 0;
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
   size_t nnz_rows() const { return row_idx.size(); }
@@ -184,7 +189,8 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
-                   &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG};
+                   &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
+                   &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -821,6 +827,208 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   HIPCHK(hipGetLastError());
   const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (solve_time) for (int b = 0; b < B; ++b) solve_time[b] = el;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shor minors: generate_rank1_matrix_completion_Shor_constraints_indexes (OMC.jl:2545-2612) and
+// generate_violated_Shor_minors (OMC.jl:2614-2640).  Kernels in omc_shor.hip; the host only sequences the segments.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ShorSeg { int kind, la, lb; };
+static void shor_segments(int n_classes, const int* classes, bool dedup, std::vector<ShorSeg>& segs) {
+  bool seen[5] = {false, false, false, false, false};
+  for (int c = 0; c < n_classes; ++c) {
+    const int p = classes[c];
+    if (p < 0 || p > 4) continue;                 // the reference's if/elseif chain has no branch for other values
+    if (dedup) { if (seen[p]) continue; seen[p] = true; }
+    if (p == 4) segs.push_back({SH_COMBO, SH_BOTH, 0});                                       // OMC.jl:2556-2561
+    else if (p == 3) segs.push_back({SH_PRODUCT, SH_BOTH, SH_XOR});                           // 2562-2569
+    else if (p == 2) { segs.push_back({SH_PRODUCT, SH_BOTH, SH_NONE}); segs.push_back({SH_COMBO, SH_XOR, 0}); }  // 2570-2584
+    else if (p == 1) segs.push_back({SH_PRODUCT, SH_XOR, SH_NONE});                           // 2585-2596
+    else segs.push_back({SH_COMBO, SH_NONE, 0});                                              // 2597-2608
+  }
+}
+static int shor_prepare(omc_instance* h) {
+  if (h->shor_ready) return 0;
+  const int n = h->n, m = h->m;
+  if (m > 8192) return fail(OMC_ERR_UNSUPPORTED, "Shor enumeration supports m <= 8192 in this build");
+  HIPCHK(hipSetDevice(h->device));
+  const int W = (m + 63) / 64;
+  std::vector<uint64_t> bits((size_t)n * W, 0);
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < n; ++i)
+      if (h->mask[(size_t)j * n + i]) bits[(size_t)i * W + (j >> 6)] |= (1ULL << (j & 63));
+  const long long np = (long long)n * (n - 1) / 2;
+  int rc;
+  if ((rc = upload(h->sbits, bits.data(), bits.size() * 8, h->stream))) return rc;
+  if ((rc = h->scb.ensure((size_t)std::max(np, 1LL) * 4)) || (rc = h->scx.ensure((size_t)std::max(np, 1LL) * 4)) ||
+      (rc = h->scz.ensure((size_t)std::max(np, 1LL) * 4)) || (rc = h->soff.ensure((size_t)std::max(np, 1LL) * 8)) ||
+      (rc = h->stot.ensure(64)) || (rc = h->shist.ensure(256 * 8)) || (rc = h->scnt.ensure(64)))
+    return rc;
+  omc_shor_launch_pair_counts(n, m, W, h->sbits.as<uint64_t>(), np, h->scb.as<int>(), h->scx.as<int>(), h->scz.as<int>(), h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));   // `bits` is a host temporary
+  h->shor_W = W; h->shor_pairs = np; h->shor_ready = true;
+  return 0;
+}
+// scan segment `sg` with offsets starting at `base`; returns its total
+static int shor_scan(omc_instance* h, const ShorSeg& sg, long long base, long long* total) {
+  omc_shor_launch_seg_scan(sg.kind, sg.la, sg.lb, h->scb.as<int>(), h->scx.as<int>(), h->scz.as<int>(), h->shor_pairs, base,
+                           h->soff.as<long long>(), h->stot.as<long long>(), h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(total, h->stot.p, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int omc_shor_count(omc_instance* h, int n_classes, const int* num_entries_present, int64_t* count_per_class) {
+  if (!h || (n_classes > 0 && !num_entries_present) || !count_per_class) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  int rc = shor_prepare(h);
+  if (rc) return rc;
+  for (int c = 0; c < n_classes; ++c) {
+    std::vector<ShorSeg> segs;
+    shor_segments(1, num_entries_present + c, false, segs);
+    long long tot = 0;
+    for (const ShorSeg& sg : segs) { long long t = 0; if ((rc = shor_scan(h, sg, 0, &t))) return rc; tot += t; }
+    count_per_class[c] = tot;
+  }
+  return 0;
+}
+
+int omc_shor_indexes(omc_instance* h, int n_classes, const int* num_entries_present, int64_t capacity, int64_t* out, int64_t* count) {
+  if (!h || (n_classes > 0 && !num_entries_present) || !count) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  int rc = shor_prepare(h);
+  if (rc) return rc;
+  std::vector<ShorSeg> segs;
+  shor_segments(n_classes, num_entries_present, false, segs);
+  std::vector<long long> tot(segs.size(), 0);
+  long long total = 0;
+  for (size_t q = 0; q < segs.size(); ++q) { if ((rc = shor_scan(h, segs[q], 0, &tot[q]))) return rc; total += tot[q]; }
+  *count = total;
+  if (!out || capacity < total || total == 0) return 0;      // size query (or nothing to write)
+  if ((rc = h->sout.ensure((size_t)total * 32))) return rc;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, h->stream));
+  long long base = 0;
+  for (size_t q = 0; q < segs.size(); ++q) {
+    long long t = 0;
+    if ((rc = shor_scan(h, segs[q], base, &t))) return rc;
+    omc_shor_launch_enum_tuples(h->n, h->m, h->shor_W, h->sbits.as<uint64_t>(), segs[q].kind, segs[q].la, segs[q].lb,
+                                h->soff.as<long long>(), h->shor_pairs, h->sout.as<long long>(), h->stream);
+    HIPCHK(hipGetLastError());
+    base += t;
+  }
+  HIPCHK(hipEventRecord(e1, h->stream));
+  HIPCHK(hipMemcpyAsync(out, h->sout.p, (size_t)total * 32, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  h->shor_last_ms = ms; h->shor_last_candidates = total;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+}
+
+int omc_violated_shor_minors(omc_instance* h, const double* X, int n_classes, const int* num_entries_present, int64_t n_existing,
+                             const int64_t* existing, int n_minors, double* scores, int64_t* minors, int* n_out) {
+  if (!h || !X || (n_classes > 0 && !num_entries_present) || (n_existing > 0 && !existing) || !n_out) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (n_minors < 0 || n_existing < 0) return fail(OMC_ERR_ARGUMENT, "negative count");
+  if (n_minors > 0 && (!scores || !minors)) return fail(OMC_ERR_ARGUMENT, "NULL output");
+  *n_out = 0;
+  int rc = shor_prepare(h);
+  if (rc) return rc;
+  const int n = h->n, m = h->m, k = h->k;
+  std::vector<ShorSeg> segs;
+  shor_segments(n_classes, num_entries_present, true, segs);   // setdiff! also removes duplicates (OMC.jl:2626)
+  std::vector<long long> tot(segs.size(), 0);
+  long long N = 0;
+  for (size_t q = 0; q < segs.size(); ++q) { if ((rc = shor_scan(h, segs[q], 0, &tot[q]))) return rc; N += tot[q]; }
+  if (N == 0 || n_minors == 0) return 0;
+  // keys of the existing constraints, sorted and unique
+  std::vector<uint64_t> ex; ex.reserve((size_t)n_existing);
+  for (int64_t e = 0; e < n_existing; ++e) {
+    const int64_t i1 = existing[4 * e] - 1, i2 = existing[4 * e + 1] - 1, j1 = existing[4 * e + 2] - 1, j2 = existing[4 * e + 3] - 1;
+    if (i1 < 0 || i1 >= n || i2 < 0 || i2 >= n || j1 < 0 || j1 >= m || j2 < 0 || j2 >= m) continue;   // cannot equal any candidate
+    ex.push_back((((uint64_t)i1 * n + i2) * m + j1) * m + j2 + 1);
+  }
+  std::sort(ex.begin(), ex.end()); ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
+  if ((rc = upload(h->sexist, ex.data(), ex.size() * 8, h->stream))) return rc;
+  if ((rc = upload(h->bXin, X, sizeof(double) * (size_t)k * n * m, h->stream))) return rc;
+  if ((rc = h->shi.ensure((size_t)N * 8)) || (rc = h->slo.ensure((size_t)N * 8))) return rc;
+  HIPCHK(hipMemsetAsync(h->scnt.p, 0, 16, h->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, h->stream));
+  long long base = 0;
+  for (size_t q = 0; q < segs.size(); ++q) {
+    long long t = 0;
+    if ((rc = shor_scan(h, segs[q], base, &t))) return rc;
+    omc_shor_launch_enum_keys(n, m, h->shor_W, h->sbits.as<uint64_t>(), segs[q].kind, segs[q].la, segs[q].lb, h->soff.as<long long>(),
+                              h->shor_pairs, h->bXin.as<double>(), k, h->sexist.as<uint64_t>(), (long long)ex.size(),
+                              h->shi.as<uint64_t>(), h->slo.as<uint64_t>(), h->scnt.as<unsigned long long>(), h->stream);
+    HIPCHK(hipGetLastError());
+    base += t;
+  }
+  unsigned long long excluded = 0;
+  HIPCHK(hipMemcpyAsync(&excluded, h->scnt.p, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const long long V = N - (long long)excluded;
+  const long long K = std::min<long long>(n_minors, V);      // fewer candidates than n_minors: all of them, sorted (OMC.jl:2634-2635)
+  if (K > 0) {
+    // MSD radix select of the K largest 128-bit keys
+    const long long CAP = 8192;
+    uint64_t phi = 0, plo = 0; long long need = K; unsigned long long bin = 0;
+    for (int level = 0; level < 16; ++level) {
+      HIPCHK(hipMemsetAsync(h->shist.p, 0, 256 * 8, h->stream));
+      omc_shor_launch_hist(N, h->shi.as<uint64_t>(), h->slo.as<uint64_t>(), phi, plo, level, h->shist.as<unsigned long long>(), h->stream);
+      HIPCHK(hipGetLastError());
+      unsigned long long hist[256];
+      HIPCHK(hipMemcpyAsync(hist, h->shist.p, sizeof(hist), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      long long cum = 0; int d = 255;
+      for (; d > 0; --d) { if (cum + (long long)hist[d] >= need) break; cum += (long long)hist[d]; }
+      need -= cum; bin = hist[d];
+      if (level < 8) phi |= (uint64_t)d << (56 - 8 * level); else plo |= (uint64_t)d << (56 - 8 * (level - 8));
+      if ((long long)bin - need <= CAP) break;
+    }
+    const unsigned long long cap = (unsigned long long)(K + CAP + 16);
+    if ((rc = h->sohi.ensure(cap * 8)) || (rc = h->solo.ensure(cap * 8))) return rc;
+    HIPCHK(hipMemsetAsync((char*)h->scnt.p + 8, 0, 8, h->stream));
+    omc_shor_launch_emit(N, h->shi.as<uint64_t>(), h->slo.as<uint64_t>(), phi, plo, h->sohi.as<uint64_t>(), h->solo.as<uint64_t>(),
+                         h->scnt.as<unsigned long long>() + 1, cap, h->stream);
+    HIPCHK(hipGetLastError());
+    unsigned long long got = 0;
+    HIPCHK(hipMemcpyAsync(&got, (char*)h->scnt.p + 8, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(e1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (got > cap || (long long)got < K) return fail(OMC_ERR_ARGUMENT, "internal: radix select emitted an unexpected number of keys");
+    std::vector<uint64_t> ohi(got), olo(got);
+    HIPCHK(hipMemcpy(ohi.data(), h->sohi.p, got * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(olo.data(), h->solo.p, got * 8, hipMemcpyDeviceToHost));
+    std::vector<size_t> ord(got);
+    for (size_t i = 0; i < got; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return ohi[a] != ohi[b] ? ohi[a] > ohi[b] : olo[a] > olo[b]; });
+    for (long long r = 0; r < K; ++r) {
+      const size_t i = ord[(size_t)r];
+      double sc; memcpy(&sc, &ohi[i], 8);
+      scores[r] = sc;
+      uint64_t key = olo[i] - 1;
+      const uint64_t j2 = key % m; key /= m;
+      const uint64_t j1 = key % m; key /= m;
+      const uint64_t i2 = key % n; const uint64_t i1 = key / n;
+      minors[4 * r] = (int64_t)i1 + 1; minors[4 * r + 1] = (int64_t)i2 + 1; minors[4 * r + 2] = (int64_t)j1 + 1; minors[4 * r + 3] = (int64_t)j2 + 1;
+    }
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    h->shor_last_ms = ms; h->shor_last_candidates = N;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *n_out = (int)K;
+  return 0;
+}
+
+int omc_shor_last_stats(omc_instance* h, double* ms, int64_t* candidates) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (ms) *ms = h->shor_last_ms;
+  if (candidates) *candidates = h->shor_last_candidates;
   return 0;
 }
 

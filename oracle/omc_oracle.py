@@ -275,8 +275,10 @@ def violated_shor_minors(X3, indices, num_entries_present_list, existing, n_mino
         seen.add(t); uniq.append(t)
     scored = []
     for (i1, i2, j1, j2) in uniq:
-        s = float(np.abs(X3[:, i1 - 1, j1 - 1] * X3[:, i2 - 1, j2 - 1]
-                         - X3[:, i1 - 1, j2 - 1] * X3[:, i2 - 1, j1 - 1]).sum())
+        terms = np.abs(X3[:, i1 - 1, j1 - 1] * X3[:, i2 - 1, j2 - 1] - X3[:, i1 - 1, j2 - 1] * X3[:, i2 - 1, j1 - 1])
+        s = 0.0
+        for t in range(terms.shape[0]):     # left-to-right, as Julia's sum over a short vector
+            s = s + float(terms[t])
         scored.append((s, (i1, i2, j1, j2)))
     scored.sort(key=lambda t: (t[0], t[1]), reverse=True)   # Julia sorts tuples lexicographically, rev
     return scored[:n_minors] if len(scored) >= n_minors else scored

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(f).startswith("shor_"))
+SHOR = os.path.join(HERE, "golden", "shor_9x13_k2.npz")
 DIR_NAMES = {0: "left", 1: "middle", 2: "right", 3: "inner_left", 4: "inner_right"}
 REL = 2e-6   # objective tolerance: both sides are certified to 1e-6 of the optimum when OPTIMAL
 
@@ -50,4 +51,31 @@ def test_hip_reproduces_golden(f, omc):
             assert o["objective"] - o["dual_bound"] <= 1.01e-6 * max(1.0, abs(o["objective"]))
         assert o["lambda_min"][0] == pytest.approx(float(z["lmin"][b]), abs=1e-5)
         assert eng.evaluate_objective(o["X"]) == pytest.approx(float(z["eval_obj"][b]), rel=1e-5)
+    eng.close()
+
+
+def test_oracle_reproduces_shor_golden(orc):
+    z = np.load(SHOR, allow_pickle=False)
+    for p in (4, 3, 2, 1, 0):
+        assert np.array_equal(np.array(orc.shor_constraints_indexes(z["mask"], [p]), dtype=np.int64).reshape(-1, 4), z["idx_%d" % p])
+    assert np.array_equal(np.array(orc.shor_constraints_indexes(z["mask"], [2, 4]), dtype=np.int64).reshape(-1, 4), z["idx_2_4"])
+    ex = [tuple(int(v) for v in t) for t in z["existing"]]
+    for nm, e in (("first", []), ("second", ex)):
+        got = orc.violated_shor_minors(z["X3"], z["mask"], [4, 3], e, 12)
+        assert np.array_equal(np.array([t for _, t in got], dtype=np.int64), z[nm + "_minors"])
+        assert np.array_equal(np.array([s for s, _ in got]), z[nm + "_scores"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_shor_golden(omc):
+    z = np.load(SHOR, allow_pickle=False)
+    eng = omc.Engine(z["A"], z["mask"], 80.0, int(z["X3"].shape[0]))
+    for p in (4, 3, 2, 1, 0):
+        assert np.array_equal(eng.generate_rank1_matrix_completion_Shor_constraints_indexes([p]), z["idx_%d" % p])
+    assert np.array_equal(eng.generate_rank1_matrix_completion_Shor_constraints_indexes([2, 4]), z["idx_2_4"])
+    ex = [tuple(int(v) for v in t) for t in z["existing"]]
+    for nm, e in (("first", []), ("second", ex)):
+        got = eng.generate_violated_Shor_minors(z["X3"], [4, 3], e, 12)
+        assert np.array_equal(np.array([t for _, t in got], dtype=np.int64), z[nm + "_minors"])
+        assert np.array_equal(np.array([s for s, _ in got]), z[nm + "_scores"])
     eng.close()

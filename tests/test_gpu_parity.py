@@ -267,3 +267,75 @@ def test_large_order_uses_l2_resident_path(have_gpu, omc, orc):
     assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
     assert g["dual_bound"] == pytest.approx(r["dual_bound"], rel=1e-5)
     eng.close()
+
+
+# ---- Shor minors (rows a10 / a11): integer work, bit-exact against the oracle ----------------------------------------
+def _shor_instance(orc, omc, n, m, k, frac, seed):
+    rng = np.random.default_rng(seed)
+    mask = rng.random((n, m)) < frac
+    mask[rng.integers(0, n, m), np.arange(m)] = True
+    mask[np.arange(n), rng.integers(0, m, n)] = True
+    A = rng.standard_normal((n, m))
+    return A, mask, omc.Engine(A, mask, GAMMA, k)
+
+
+@pytest.mark.parametrize("n,m,frac,seed", [(5, 6, 0.5, 0), (7, 9, 0.4, 1), (12, 20, 0.3, 2), (9, 70, 0.5, 3), (20, 130, 0.2, 4)])
+def test_shor_indexes_bit_exact(have_gpu, omc, orc, n, m, frac, seed):
+    A, mask, eng = _shor_instance(orc, omc, n, m, 1, frac, seed)
+    for cl in ([4], [3], [2], [1], [0], [4, 3, 2, 1, 0], [2, 4], [4, 4], [7], []):
+        if n * m > 1500 and (0 in cl or 1 in cl or 2 in cl) and len(cl) > 1:
+            continue                                   # keep the pure-Python oracle in seconds
+        want = np.array(orc.shor_constraints_indexes(mask, cl), dtype=np.int64).reshape(-1, 4)
+        got = eng.generate_rank1_matrix_completion_Shor_constraints_indexes(cl)
+        assert got.shape == want.shape, (cl, got.shape, want.shape)
+        assert np.array_equal(got, want), cl
+        assert np.array_equal(eng.shor_count(cl), [len(orc.shor_constraints_indexes(mask, [p])) for p in cl])
+    eng.close()
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_violated_shor_minors_bit_exact(have_gpu, omc, orc, k):
+    n, m = 10, 14
+    A, mask, eng = _shor_instance(orc, omc, n, m, k, 0.45, 10 + k)
+    rng = np.random.default_rng(5)
+    cases = {"gauss": rng.standard_normal((k, n, m)), "ties": rng.integers(-2, 3, (k, n, m)).astype(float), "zero": np.zeros((k, n, m))}
+    for name, X3 in cases.items():
+        for cl in ([4], [4, 3], [3, 2, 1, 0, 4]):
+            first = orc.violated_shor_minors(X3, mask, cl, [], 7)
+            existing = [t for _, t in first[:5]] + [(1, 2, 1, 2), (n, n, m, m)]
+            for ex, nm in (([], 7), (existing, 100), (existing, 10 ** 6), ([], 0)):
+                want = orc.violated_shor_minors(X3, mask, cl, ex, nm)
+                got = eng.generate_violated_Shor_minors(X3, cl, ex, nm)
+                assert len(got) == len(want), (name, cl, nm)
+                assert [t for _, t in got] == [t for _, t in want], (name, cl, nm)
+                assert [s for s, _ in got] == [s for s, _ in want], (name, cl, nm)      # identical doubles
+    eng.close()
+
+
+def test_shor_counts_config3_size(have_gpu, omc, orc):
+    """200 x 200, 20 % observed (BASELINE config 3): counts against popcount formulas, order and uniqueness properties."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(3, seed=0)
+    eng = omc.Engine(A, mask, gamma, c["k"])
+    Mi = mask.astype(np.int64)
+    both = Mi @ Mi.T; obs = Mi.sum(1); m = mask.shape[1]
+    xor = obs[:, None] + obs[None, :] - 2 * both; none = m - obs[:, None] - obs[None, :] + both
+    iu = np.triu_indices(mask.shape[0], 1)
+    b, x, z = both[iu], xor[iu], none[iu]
+    want = {4: (b * (b - 1) // 2).sum(), 3: (b * x).sum(), 2: (b * z).sum() + (x * (x - 1) // 2).sum(), 1: (x * z).sum(), 0: (z * (z - 1) // 2).sum()}
+    got = eng.shor_count([4, 3, 2, 1, 0])
+    assert [int(v) for v in got] == [int(want[p]) for p in (4, 3, 2, 1, 0)]
+    T = eng.generate_rank1_matrix_completion_Shor_constraints_indexes([4])
+    assert len(T) == want[4]
+    assert (T[:, 0] < T[:, 1]).all() and (T[:, 2] < T[:, 3]).all()
+    assert mask[T[:, 0] - 1, T[:, 2] - 1].all() and mask[T[:, 0] - 1, T[:, 3] - 1].all() and mask[T[:, 1] - 1, T[:, 2] - 1].all() and mask[T[:, 1] - 1, T[:, 3] - 1].all()
+    key = ((T[:, 0] * 1000 + T[:, 1]) * 1000 + T[:, 2]) * 1000 + T[:, 3]
+    assert (np.diff(key) > 0).all()                     # the push order of p = 4 is lexicographic, hence also unique
+    # top-100 violated minors of a rank-1 + noise X: scores must be the 100 largest, in order
+    rng = np.random.default_rng(0)
+    X3 = (A + 0.1 * rng.standard_normal(A.shape))[None]
+    top = eng.generate_violated_Shor_minors(X3, [4], [], 100)
+    sc = np.abs(X3[0][T[:, 0] - 1, T[:, 2] - 1] * X3[0][T[:, 1] - 1, T[:, 3] - 1] - X3[0][T[:, 0] - 1, T[:, 3] - 1] * X3[0][T[:, 1] - 1, T[:, 2] - 1])
+    order = np.lexsort((key, sc))[::-1][:100]
+    assert [t for _, t in top] == [tuple(int(v) for v in T[i]) for i in order]
+    assert [s for s, _ in top] == [float(sc[i]) for i in order]
+    eng.close()

@@ -45,5 +45,30 @@ def main():
                             iters=np.array([r["iters"] for r in recs]), lmin=np.array([r["lmin"] for r in recs]),
                             eval_obj=np.array([r["eval_obj"] for r in recs]))
 
+def make_shor_golden():
+    """Shor-minor fixtures (integer work): mask, X and the oracle's index lists / top violated minors."""
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    rng = np.random.default_rng(77)
+    n, m, k = 9, 13, 2
+    mask = rng.random((n, m)) < 0.45
+    mask[rng.integers(0, n, m), np.arange(m)] = True; mask[np.arange(n), rng.integers(0, m, n)] = True
+    X3 = np.round(rng.standard_normal((k, n, m)) * 4) / 4          # quarter-integers: exact products, many tied scores
+    rec = dict(mask=mask, X3=X3, A=rng.standard_normal((n, m)))
+    for p in (4, 3, 2, 1, 0):
+        rec["idx_%d" % p] = np.array(orc.shor_constraints_indexes(mask, [p]), dtype=np.int64).reshape(-1, 4)
+    rec["idx_2_4"] = np.array(orc.shor_constraints_indexes(mask, [2, 4]), dtype=np.int64).reshape(-1, 4)
+    first = orc.violated_shor_minors(X3, mask, [4, 3], [], 12)
+    existing = np.array([t for _, t in first[:6]], dtype=np.int64)
+    second = orc.violated_shor_minors(X3, mask, [4, 3], [tuple(int(v) for v in t) for t in existing], 12)
+    rec["existing"] = existing
+    for nm, lst in (("first", first), ("second", second)):
+        rec[nm + "_scores"] = np.array([s for s, _ in lst]); rec[nm + "_minors"] = np.array([t for _, t in lst], dtype=np.int64)
+    np.savez_compressed(os.path.join(out_dir, "shor_9x13_k2.npz"), **rec)
+    print("shor fixture:", {k_: v.shape for k_, v in rec.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "shor":
+        make_shor_golden()
+    else:
+        main(); make_shor_golden()
