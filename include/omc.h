@@ -79,6 +79,12 @@ typedef struct omc_relax_params {
   int bump_after;      /*   ... from this iteration on, at least bump_window checks apart       (100)   */
   int bump_window;     /*                                                                       (4)     */
   int slots;           /* nodes relaxed concurrently (continuous batching); 0 = min(B, 256)       (0)     */
+  int accel;           /* 1: Anderson acceleration of the ADMM fixed-point map (type II, safeguarded) (0)  */
+  int aa_mem;          /*   differences kept (<= 10)                                                 (10)    */
+  int aa_every;        /*   an extrapolated point every this many iterations                         (5)     */
+  int aa_start;        /*   first iteration that records history                                     (50)    */
+  double aa_reg;       /*   Tikhonov weight of the least squares, relative to mean diag              (1e-10) */
+  double aa_safeguard; /*   the point is kept when the next fixed-point residual <= this x the last  (1.0)   */
 } omc_relax_params;
 
 void omc_relax_params_default(omc_relax_params* p);
@@ -177,7 +183,8 @@ int omc_shor_last_stats(omc_instance* h, double* ms, int64_t* candidates);
 #define OMC_KERNEL_CHECK 3
 #define OMC_KERNEL_SETUP 4
 #define OMC_KERNEL_SMALL 5
-#define OMC_KERNEL_NCLASS 6
+#define OMC_KERNEL_ACCEL 6
+#define OMC_KERNEL_NCLASS 7
 /* info[8]: solve seconds, total Jacobi sweeps of k_cone, rho, r_max, LDS flags (cone, global, small), R_max */
 int omc_last_solver_info(omc_instance* h, double* info);
 /* diagnostic builds (-DOMC_STAMPS) only: accumulated s_memtime ticks per kernel phase of node 0; zeros otherwise */
@@ -185,6 +192,8 @@ int omc_debug_stamps(omc_instance* h, double* out32);
 /* diagnostic builds only: per-slot counters, out[c * slots + b]: c = 0 colprox wave cycles, 1 factorizations, 2 cone cycles,
  * 3 cone calls, 4 global cycles, 5 small cycles (zeros otherwise) */
 int omc_debug_diag(omc_instance* h, double* out);
+/* accepted / rejected extrapolated points of the node last relaxed in every slot (diagnostics; needs accel = 1) */
+int omc_debug_aa(omc_instance* h, int* accepted, int* rejected);
 /* last primal / dual ADMM residuals of every node of the staged batch (diagnostics) */
 int omc_debug_residuals(omc_instance* h, double* rp, double* rd);
 int omc_last_kernel_stats(omc_instance* h, int64_t* launches /*NCLASS*/, double* ms /*NCLASS*/,

@@ -14,7 +14,7 @@ EXPORTS = [
     "omc_relax_params_default", "omc_last_error", "omc_version", "omc_device_count", "omc_instance_create",
     "omc_instance_create_bits", "omc_instance_destroy", "omc_relax_batch", "omc_relax_stage", "omc_relax_solve",
     "omc_relax_fetch", "omc_altmin_batch", "omc_evaluate_objective", "omc_separation_batch", "omc_round_Y_batch",
-    "omc_last_kernel_stats", "omc_last_solver_info", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag",
+    "omc_last_kernel_stats", "omc_last_solver_info", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
     "omc_shor_count", "omc_shor_indexes", "omc_violated_shor_minors", "omc_shor_last_stats",
 ]
 
@@ -23,7 +23,8 @@ class RelaxParams(C.Structure):
     _fields_ = [("eps_gap", C.c_double), ("eps_feas", C.c_double), ("max_iters", C.c_int), ("check_every", C.c_int),
                 ("rho_scale", C.c_double), ("rho_f_ratio", C.c_double), ("relax", C.c_double), ("time_limit", C.c_double),
                 ("reference_quirk_q1", C.c_int), ("breakpoints", C.c_int), ("stall_checks", C.c_int), ("bump_max", C.c_int), ("bump_ratio", C.c_double),
-                ("bump_factor", C.c_double), ("bump_after", C.c_int), ("bump_window", C.c_int), ("slots", C.c_int)]
+                ("bump_factor", C.c_double), ("bump_after", C.c_int), ("bump_window", C.c_int), ("slots", C.c_int),
+                ("accel", C.c_int), ("aa_mem", C.c_int), ("aa_every", C.c_int), ("aa_start", C.c_int), ("aa_reg", C.c_double), ("aa_safeguard", C.c_double)]
 
 
 class OmcError(RuntimeError):
@@ -67,6 +68,7 @@ def load():
     lib.omc_debug_stamps.argtypes = [vp, vp]
     lib.omc_debug_residuals.argtypes = [vp, vp, vp]
     lib.omc_debug_diag.argtypes = [vp, vp]
+    lib.omc_debug_aa.argtypes = [vp, vp, vp]
     lib.omc_shor_count.argtypes = [vp, C.c_int, vp, vp]
     lib.omc_shor_indexes.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp]
     lib.omc_violated_shor_minors.argtypes = [vp, vp, C.c_int, vp, C.c_int64, vp, C.c_int, vp, vp, vp]

@@ -23,7 +23,7 @@ CUT_TYPES = {"linear": 0, "linear2": 1, "linear3": 2}
 DIR_CODES = {"left": 0, "middle": 1, "right": 2, "inner_left": 3, "inner_right": 4}
 BREAKPOINTS = {"smallest_1_eigvec": 1, "smallest_2_eigvec": 2}
 STATUS_NAMES = {0: "OPTIMAL", 1: "SLOW_PROGRESS", 2: "TIME_LIMIT", 3: "INFEASIBLE"}
-KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small"]
+KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small", "accel"]
 
 
 def default_params(**kw) -> RelaxParams:
@@ -138,9 +138,9 @@ class Engine:
         return self.fetch(want_Y, want_X, want_Theta)
 
     def kernel_stats(self):
-        la = np.zeros(6, np.int64); ms = np.zeros(6); un = np.zeros(6, np.int64)
+        nc = len(KERNEL_CLASSES); la = np.zeros(nc, np.int64); ms = np.zeros(nc); un = np.zeros(nc, np.int64)
         _lib.check(self._lib.omc_last_kernel_stats(self._h, _lib.ptr(la), _lib.ptr(ms), _lib.ptr(un)))
-        return {KERNEL_CLASSES[i]: dict(launches=int(la[i]), ms=float(ms[i]), units=int(un[i])) for i in range(6)}
+        return {KERNEL_CLASSES[i]: dict(launches=int(la[i]), ms=float(ms[i]), units=int(un[i])) for i in range(nc)}
 
     def solver_info(self):
         info = np.zeros(8)

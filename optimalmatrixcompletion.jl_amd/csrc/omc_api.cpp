@@ -63,6 +63,7 @@ struct omc_instance {
   // batch workspace
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
+  DevBuf baaF, baaG, baaZ, baaS, baaI;
   DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow;
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
   OmcWS ws{};
@@ -98,6 +99,7 @@ void omc_relax_params_default(omc_relax_params* p) {
   p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
   p->bump_max = 6; p->bump_ratio = 4.0; p->bump_factor = 4.0; p->bump_after = 100; p->bump_window = 4; p->slots = 0;
+  p->accel = 0; p->aa_mem = 10; p->aa_every = 5; p->aa_start = 50; p->aa_reg = 1e-10; p->aa_safeguard = 1.0;
 }
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
@@ -190,7 +192,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
-                   &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
+                   &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -367,6 +369,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   w.rho_f_ratio = P.rho_f_ratio;
   w.bump_max = P.bump_max; w.bump_ratio = P.bump_ratio; w.bump_factor = P.bump_factor; w.bump_after = P.bump_after;
   w.bump_gap = P.bump_window * std::max(1, P.check_every);
+  w.accel = P.accel ? 1 : 0; w.aa_mem = std::max(2, std::min(P.aa_mem, AA_MAXMEM)); w.aa_every = std::max(1, P.aa_every);
+  w.aa_start = std::max(2, P.aa_start); w.aa_reg = P.aa_reg; w.aa_safeguard = P.aa_safeguard;
   {
     std::vector<double> hr(B, w.rho);
     if (h->rho_scale_per_node.size() == (size_t)B)
@@ -419,6 +423,15 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   w.cst = sc + 6 * sB; w.rp = sc + 7 * sB; w.rd = sc + 8 * sB; w.lmin = sc + 9 * sB;  // lmin uses 2B (slots 9,10)
   w.objprev = sc + 11 * sB; w.lbprev = sc + 12 * sB; w.fro2 = sc + 13 * sB; w.bfac = sc + 14 * sB;
   w.bx = h->bbx.as<double>();
+  if (w.accel) {
+    w.aa_dim = 4 * n * n + 2 * rmax * k + k * k + h->nnz;
+    const size_t ring = sB * (size_t)(w.aa_mem + 1) * w.aa_dim * 8;
+    ENS(h->baaF, ring); ENS(h->baaG, ring); ENS(h->baaZ, sB * (size_t)w.aa_dim * 8); ENS(h->baaS, sB * 8); ENS(h->baaI, sB * 6 * sizeof(int));
+    w.aa_F = h->baaF.as<double>(); w.aa_G = h->baaG.as<double>(); w.aa_zin = h->baaZ.as<double>(); w.aa_fn = h->baaS.as<double>();
+    int* ai = h->baaI.as<int>();
+    w.aa_hist = ai; w.aa_head = ai + sB; w.aa_pending = ai + 2 * sB; w.aa_valid = ai + 3 * sB; w.aa_nacc = ai + 4 * sB; w.aa_nrej = ai + 5 * sB;
+    HIPCHK(hipMemsetAsync(ai, 0, sB * 6 * sizeof(int), h->stream));
+  }
   int* ip = h->bint.as<int>();
   w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB; w.vvalid = ip + 5 * sB; w.nbump = ip + 6 * sB; w.lastbump = ip + 7 * sB;
   {
@@ -582,7 +595,10 @@ int omc_relax_solve(omc_instance* h) {
     else TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone(&w, CONE_CLIP01, h->cone_use_lds, h->cone_lds, s));
     TIMED(OMC_KERNEL_SMALL, nactive, omc_launch_small(&w, SMALL_PROJ, h->small_use_lds, h->small_lds, s));
     TIMED(OMC_KERNEL_GLOBAL, nactive, omc_launch_global(&w, h->glob_use_lds, h->glob_lds, s));
-    if (it % check != 0) continue;
+    if (it % check != 0) {
+      if (w.accel) TIMED(OMC_KERNEL_ACCEL, nactive, omc_launch_aa(&w, s));
+      continue;
+    }
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     timed_out = el > P.time_limit;
     TIMED(OMC_KERNEL_CHECK, nactive, {
@@ -592,6 +608,7 @@ int omc_relax_solve(omc_instance* h) {
       omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
       omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, s);      // per-slot iteration cap is applied on the device
       if (w.bump_max > 0) omc_launch_rho_rescale(&w, s);
+      if (w.accel) omc_launch_aa(&w, s);      // after the certificate (computed on an image of the map), skips finished slots
     });
     HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * S, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1042,6 +1059,13 @@ int omc_debug_residuals(omc_instance* h, double* rp, double* rd) {
 int omc_debug_stamps(omc_instance* h, double* out32) {
   if (!h || !out32 || !h->ws.stamps) return fail(OMC_ERR_ARGUMENT, "no stamps");
   HIPCHK(hipMemcpy(out32, h->ws.stamps, 32 * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int omc_debug_aa(omc_instance* h, int* accepted, int* rejected) {
+  if (!h || !accepted || !rejected || !h->ws.accel || !h->ws.aa_nacc) return fail(OMC_ERR_ARGUMENT, "acceleration is off or nothing staged");
+  HIPCHK(hipMemcpy(accepted, h->ws.aa_nacc, 4 * (size_t)h->ws.B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rejected, h->ws.aa_nrej, 4 * (size_t)h->ws.B, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -83,7 +83,15 @@ struct OmcWS {
   double* small_scratch; size_t small_scratch_stride;
   double* chk_scratch;   // B*n*k
   double* stamps;        // 32 doubles (diagnostic builds)
+  // Anderson acceleration (k_aa): per slot a ring of (aa_mem + 1) residuals f = T(z) - z and images g = T(z) of the state
+  // vector z = (Y, Yp, D1, D3, Vt, D3V, D3T, alpha), the input zin of the running iteration, and a few scalars
+  int accel, aa_mem, aa_every, aa_start, aa_dim;
+  double aa_reg, aa_safeguard;
+  double *aa_F, *aa_G, *aa_zin;   // B*(aa_mem+1)*aa_dim, same, B*aa_dim
+  double* aa_fn;                  // B: residual norm of the last plain step while a point awaits verification
+  int *aa_hist, *aa_head, *aa_pending, *aa_valid, *aa_nacc, *aa_nrej;   // B each; aa_valid = 0 requests "copy the state into zin, forget history"
 };
+#define AA_MAXMEM 10
 
 #ifdef __cplusplus
 extern "C" {
@@ -99,6 +107,7 @@ void omc_launch_check_build(const OmcWS* w, hipStream_t s);
 void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s);
 void omc_launch_harvest(const OmcWS* w, hipStream_t s);
+void omc_launch_aa(const OmcWS* w, hipStream_t s);
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s);
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s);
 void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,

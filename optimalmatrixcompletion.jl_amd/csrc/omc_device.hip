@@ -96,6 +96,7 @@ __global__ void k_setup(OmcWS w) {
   for (int e = tid; e < w.Rmax; e += T) w.lam[(size_t)b * w.Rmax + e] = 0.0;
   if (tid == 0) {
     w.init[b] = 0; w.rho_b[b] = w.rho_node[nb];
+    if (w.accel) { w.aa_valid[b] = 0; w.aa_hist[b] = 0; w.aa_head[b] = 0; w.aa_pending[b] = 0; w.aa_nacc[b] = 0; w.aa_nrej[b] = 0; }
     w.done[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0; w.nbump[b] = 0; w.lastbump[b] = 0; w.bfac[b] = 1.0;
     w.obj[b] = 1e300; w.objout[b] = 1e300; w.objprev[b] = 1e300; w.lbprev[b] = -1e300; w.lb[b] = -1e300; w.rp[b] = 1e300; w.rd[b] = 1e300;
   }
@@ -1431,7 +1432,179 @@ __global__ void __launch_bounds__(256) k_rho_rescale(OmcWS w) {
     w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
   }
   fr2 = block_sum(fr2, red);
-  if (tid == 0) { w.fro2[b] = fr2; w.bfac[b] = 1.0; }
+  if (tid == 0) { w.fro2[b] = fr2; w.bfac[b] = 1.0; if (w.accel) w.aa_valid[b] = 0; }   // the map changed: restart the history
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_aa: Anderson acceleration (type II) of the ADMM fixed-point map T, one workgroup per slot, after every iteration.
+//   z = (Y, Yp, D1, D3, Vt, D3V, D3T, alpha) is the state an iteration reads; the arrays hold g = T(z) when this runs.
+//   Every iteration (from aa_start on): f = g - zin, push (f, g) on the ring.  Every aa_every-th iteration, with h >= 3
+//   entries: gamma = argmin || f - dF gamma ||^2 + reg (normal equations on the h-1 residual differences, Cholesky),
+//   z+ = g - dG gamma replaces the state.  The point is verified by the NEXT ordinary iteration: if its residual
+//   ||T(z+) - z+|| exceeds aa_safeguard * ||f||, the state is put back to g and the history is dropped; otherwise the
+//   iteration simply continues from T(z+) -- a verified point costs no extra evaluation of T.
+//   Certificates (k_check_*) run before this kernel, i.e. on images of T only.
+// ---------------------------------------------------------------------------------------------------------
+struct AaSeg { double* p; int len; };
+__global__ void __launch_bounds__(512) k_aa(OmcWS w) {
+  __shared__ double red[32];
+  __shared__ double s_H[AA_MAXMEM * AA_MAXMEM], s_rhs[AA_MAXMEM], s_gam[AA_MAXMEM];
+  __shared__ int s_ok;
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b]) return;
+  const int it = w.iters[b];
+  if (it < w.aa_start - 1) return;
+  const int n = w.n, k = w.k, rm = w.rmax, dim = w.aa_dim, M1 = w.aa_mem + 1;
+  AaSeg seg[8] = {{w.Y + (size_t)b * n * n, n * n}, {w.Yp + (size_t)b * n * n, n * n}, {w.D1 + (size_t)b * n * n, n * n},
+                  {w.D3 + (size_t)b * n * n, n * n}, {w.Vt + (size_t)b * rm * k, rm * k}, {w.D3V + (size_t)b * rm * k, rm * k},
+                  {w.D3T + (size_t)b * k * k, k * k}, {w.alpha + (size_t)b * w.nnz, w.nnz}};
+  double* zin = w.aa_zin + (size_t)b * dim;
+  double* Fh = w.aa_F + (size_t)b * M1 * dim;
+  double* Gh = w.aa_G + (size_t)b * M1 * dim;
+  auto rebuild_cone_input = [&]() {   // Mbuf = Y - D1 (zero padded), fro2
+    __syncthreads();
+    const int NP = w.np16;
+    double fr2 = 0.0;
+    for (int e = tid; e < n * n; e += T) {
+      const int i = e % n, j = e / n;
+      const double mv = seg[0].p[e] - seg[2].p[e];
+      w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
+    }
+    fr2 = block_sum(fr2, red);
+    if (tid == 0) w.fro2[b] = fr2;
+  };
+  if (!w.aa_valid[b]) {   // first use, new node or a penalty bump: zin = state, empty history
+    int o = 0;
+    for (int sgi = 0; sgi < 8; ++sgi) { for (int e = tid; e < seg[sgi].len; e += T) zin[o + e] = seg[sgi].p[e]; o += seg[sgi].len; }
+    __syncthreads();
+    if (tid == 0) { w.aa_valid[b] = 1; w.aa_hist[b] = 0; w.aa_head[b] = 0; w.aa_pending[b] = 0; }
+    return;
+  }
+  int hist = w.aa_hist[b], head = w.aa_head[b];
+  const int pending = w.aa_pending[b];
+  const int latest = (head + hist - 1 + M1) % M1;            // meaningful when hist > 0
+  const int slot = (hist < M1) ? (head + hist) % M1 : head;   // where this iteration's (f, g) goes
+  // ---- pass 1: f = g - zin, tentative push, ||f|| ----------------------------------------------------------------
+  double acc = 0.0;
+  {
+    int o = 0;
+    double* Fn = Fh + (size_t)slot * dim; double* Gn = Gh + (size_t)slot * dim;
+    for (int sgi = 0; sgi < 8; ++sgi) {
+      for (int e = tid; e < seg[sgi].len; e += T) {
+        const double g = seg[sgi].p[e], f = g - zin[o + e];
+        Fn[o + e] = f; Gn[o + e] = g; acc += f * f;
+      }
+      o += seg[sgi].len;
+    }
+  }
+  const double fn = sqrt(block_sum(acc, red));
+  if (pending && !(fn <= w.aa_safeguard * w.aa_fn[b])) {
+    // reject: back to the image of the last plain step (ring entry `latest`), forget the history
+    const double* Gl = Gh + (size_t)latest * dim;
+    int o = 0;
+    for (int sgi = 0; sgi < 8; ++sgi) {
+      for (int e = tid; e < seg[sgi].len; e += T) { const double v = Gl[o + e]; seg[sgi].p[e] = v; zin[o + e] = v; }
+      o += seg[sgi].len;
+    }
+    rebuild_cone_input();
+    if (tid == 0) { w.aa_hist[b] = 0; w.aa_head[b] = 0; w.aa_pending[b] = 0; w.aa_nrej[b] += 1; }
+    return;
+  }
+  if (pending && tid == 0) w.aa_nacc[b] += 1;
+  if (hist < M1) ++hist; else head = (head + 1) % M1;
+  const int h = hist;                                          // entries, chronological: idx(i) = (head + i) % M1
+  bool extrapolate = (it % w.aa_every == 0) && h >= 3;
+  if (extrapolate) {
+    // ---- Gram matrix of the residual differences and right-hand side: one pass over the ring ---------------------
+    const int nd = h - 1;
+    double hacc[AA_MAXMEM * (AA_MAXMEM + 1) / 2], racc[AA_MAXMEM];
+#pragma unroll
+    for (int i = 0; i < AA_MAXMEM * (AA_MAXMEM + 1) / 2; ++i) hacc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < AA_MAXMEM; ++i) racc[i] = 0.0;
+    const double* Fl = Fh + (size_t)((head + h - 1) % M1) * dim;
+    for (int e = tid; e < dim; e += T) {
+      double d[AA_MAXMEM];
+      double prev = Fh[(size_t)(head % M1) * dim + e];
+#pragma unroll
+      for (int i = 0; i < AA_MAXMEM; ++i) {
+        if (i < nd) { const double cur = Fh[(size_t)((head + i + 1) % M1) * dim + e]; d[i] = cur - prev; prev = cur; } else d[i] = 0.0;
+      }
+      const double fe = Fl[e];
+#pragma unroll
+      for (int i = 0; i < AA_MAXMEM; ++i) {
+        racc[i] += d[i] * fe;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) hacc[i * (i + 1) / 2 + j] += d[i] * d[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < AA_MAXMEM; ++i) {
+      const double rv = block_sum(racc[i], red);
+      if (tid == 0) s_rhs[i] = rv;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const double hv = block_sum(hacc[i * (i + 1) / 2 + j], red);
+        if (tid == 0) { s_H[i * AA_MAXMEM + j] = hv; s_H[j * AA_MAXMEM + i] = hv; }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double tr = 0.0;
+      for (int i = 0; i < nd; ++i) tr += s_H[i * AA_MAXMEM + i];
+      const double ridge = w.aa_reg * tr / nd;
+      int ok = (tr > 0.0) && (tr < 1e300);
+      for (int i = 0; i < nd; ++i) s_H[i * AA_MAXMEM + i] += ridge;
+      // Cholesky H = L L', then two triangular solves
+      for (int c = 0; c < nd && ok; ++c) {
+        double dg = s_H[c * AA_MAXMEM + c];
+        for (int q = 0; q < c; ++q) dg -= s_H[c * AA_MAXMEM + q] * s_H[c * AA_MAXMEM + q];
+        if (!(dg > 0.0)) { ok = 0; break; }
+        dg = sqrt(dg); s_H[c * AA_MAXMEM + c] = dg;
+        for (int r2 = c + 1; r2 < nd; ++r2) {
+          double v = s_H[r2 * AA_MAXMEM + c];
+          for (int q = 0; q < c; ++q) v -= s_H[r2 * AA_MAXMEM + q] * s_H[c * AA_MAXMEM + q];
+          s_H[r2 * AA_MAXMEM + c] = v / dg;
+        }
+      }
+      if (ok) {
+        for (int i = 0; i < nd; ++i) { double v = s_rhs[i]; for (int q = 0; q < i; ++q) v -= s_H[i * AA_MAXMEM + q] * s_gam[q]; s_gam[i] = v / s_H[i * AA_MAXMEM + i]; }
+        for (int i = nd - 1; i >= 0; --i) { double v = s_gam[i]; for (int q = i + 1; q < nd; ++q) v -= s_H[q * AA_MAXMEM + i] * s_gam[q]; s_gam[i] = v / s_H[i * AA_MAXMEM + i]; }
+        for (int i = 0; i < nd; ++i) if (!(fabs(s_gam[i]) < 1e300)) ok = 0;
+      }
+      s_ok = ok;
+    }
+    __syncthreads();
+    extrapolate = s_ok != 0;
+    if (extrapolate) {
+      // ---- z+ = g - sum_i gamma_i (G_{i+1} - G_i):  coefficients of the ring entries ------------------------------
+      double cg[AA_MAXMEM + 1];
+#pragma unroll
+      for (int i = 0; i <= AA_MAXMEM; ++i) {
+        double c = 0.0;
+        if (i < h) { if (i >= 1) c -= s_gam[i - 1]; if (i < nd) c += s_gam[i]; }
+        if (i == h - 1) c += 1.0;
+        cg[i] = c;
+      }
+      int o = 0;
+      for (int sgi = 0; sgi < 8; ++sgi) {
+        for (int e = tid; e < seg[sgi].len; e += T) {
+          double v = 0.0;
+#pragma unroll
+          for (int i = 0; i <= AA_MAXMEM; ++i) if (i < h) v += cg[i] * Gh[(size_t)((head + i) % M1) * dim + o + e];
+          seg[sgi].p[e] = v; zin[o + e] = v;
+        }
+        o += seg[sgi].len;
+      }
+      rebuild_cone_input();
+    }
+  }
+  if (!extrapolate) {   // plain step: the next input is g
+    int o = 0;
+    for (int sgi = 0; sgi < 8; ++sgi) { for (int e = tid; e < seg[sgi].len; e += T) zin[o + e] = seg[sgi].p[e]; o += seg[sgi].len; }
+  }
+  __syncthreads();
+  if (tid == 0) { w.aa_hist[b] = hist; w.aa_head[b] = head; w.aa_pending[b] = extrapolate ? 1 : 0; if (extrapolate) w.aa_fn[b] = fn; }
 }
 
 // copy the results of the slots flagged `fin` to the per-node output arrays (continuous batching: a slot is re-used)
@@ -1554,6 +1727,7 @@ void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s) {
 }
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_rho_rescale, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_harvest(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_harvest, dim3(w->B), dim3(256), 0, s, *w); }
+void omc_launch_aa(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_aa, dim3(w->B), dim3(512), 0, s, *w); }
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s) { hipLaunchKernelGGL(k_make_X, dim3(64, w->Btot), dim3(256), 0, s, *w, X); }
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s) {
   hipLaunchKernelGGL(k_make_Theta, dim3(64, w->Btot), dim3(256), 0, s, *w, X, Th);

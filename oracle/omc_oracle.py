@@ -458,6 +458,13 @@ class RelaxParams:
     bump_after: int = 100        # first iteration at which a bump may happen
     bump_max: int = 6
     bump_ratio: float = 4.0
+    # Anderson acceleration (type II) of the fixed-point map, mirrored by k_aa in omc_device.hip
+    accel: int = 0               # off by default (helps small / ill-conditioned nodes, not config 2)
+    aa_mem: int = 10             # residual differences kept
+    aa_every: int = 5            # an extrapolated point every this many iterations ...
+    aa_start: int = 50           # ... from this iteration on
+    aa_reg: float = 1e-10        # Tikhonov weight of the normal equations, relative to the mean diagonal
+    aa_safeguard: float = 1.0    # the point is kept when the next fixed-point residual <= this x the last one
 
 
 def _prox_columns(inst, Yx, alpha, svals, rho_f):
@@ -653,6 +660,18 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
     stall = 0; obj_prev = math.inf; lb_prev = -math.inf
     n_bumps = 0; last_bump = 0
     Q3 = np.zeros((r + k, r + k))
+    # Anderson acceleration: state z = (Y, Yp, D1, D3, Vt, D3V, D3T, alpha); ring of (f, g) pairs; see k_aa
+    def aa_pack():
+        return np.concatenate([Y.ravel(), Yp.ravel(), D1.ravel(), D3.ravel(), Vt.ravel(), D3V.ravel(), D3T.ravel()] + [a.ravel() for a in alpha])
+    def aa_unpack(z):
+        o = 0; outm = []
+        for shp in ((n, n), (n, n), (n, n), (n, n), (r, k), (r, k), (k, k)):
+            sz = shp[0] * shp[1]; outm.append(z[o:o + sz].reshape(shp).copy()); o += sz
+        al = []
+        for a in alpha:
+            al.append(z[o:o + a.size].reshape(a.shape).copy()); o += a.size
+        return outm, al
+    aa_valid = False; aa_F = []; aa_G = []; aa_zin = None; aa_pending = None; n_aa = n_aa_rej = 0
     for it in range(1, p.max_iters + 1):
         rho_f = rho * p.rho_f_ratio
         alpha, svals, LL = _prox_columns(inst, 2.0 * Y - Yp, alpha, svals, rho_f)
@@ -718,12 +737,46 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
                 rho *= fac
                 D1 /= fac; D3 /= fac; D3V /= fac; D3T /= fac
                 n_bumps += 1; last_bump = it
+                aa_valid = False                                       # the map changed: restart the history
+        # ---- Anderson acceleration (mirrors k_aa: runs after the certificate, on the state the next iteration reads) ----
+        if p.accel and it >= p.aa_start - 1:
+            if not aa_valid:
+                aa_zin = aa_pack(); aa_F = []; aa_G = []; aa_pending = None; aa_valid = True
+                continue
+            gz = aa_pack(); f = gz - aa_zin; fn = float(np.linalg.norm(f))
+            if aa_pending is not None and not (fn <= p.aa_safeguard * aa_pending[0]):
+                (Y, Yp, D1, D3, Vt, D3V, D3T), alpha = aa_unpack(aa_pending[1])          # reject: back to the last plain image
+                aa_zin = aa_pending[1].copy(); aa_F = []; aa_G = []; aa_pending = None; n_aa_rej += 1
+                continue
+            aa_pending = None
+            aa_F.append(f); aa_G.append(gz)
+            if len(aa_F) > p.aa_mem + 1:
+                aa_F.pop(0); aa_G.pop(0)
+            done_aa = False
+            if it % p.aa_every == 0 and len(aa_F) >= 3:
+                F_ = np.array(aa_F); G_ = np.array(aa_G)
+                dF = F_[1:] - F_[:-1]; dG = G_[1:] - G_[:-1]
+                H = dF @ dF.T; rhs = dF @ f
+                tr = float(np.trace(H))
+                if 0.0 < tr < 1e300:
+                    H = H + (p.aa_reg * tr / len(H)) * np.eye(len(H))
+                    try:
+                        Lc = np.linalg.cholesky(H)
+                        gam = np.linalg.solve(Lc.T, np.linalg.solve(Lc, rhs))
+                    except np.linalg.LinAlgError:
+                        gam = None
+                    if gam is not None and np.isfinite(gam).all():
+                        zaa = gz - dG.T @ gam
+                        (Y, Yp, D1, D3, Vt, D3V, D3T), alpha = aa_unpack(zaa)
+                        aa_pending = (fn, gz); aa_zin = zaa; done_aa = True; n_aa += 1
+            if not done_aa:
+                aa_zin = gz
     obj, Lam = inst.f_value(Y, want=True)
     X = inst.X_of(Y, Lam)
     U = recover_U(Y, Q, Vt)
     out = dict(objective=obj, dual_bound=lb, Y=Y, U=U, X=X, termination_status=status,
                feasible=status != OMC_INFEASIBLE, solve_time=time.time() - t0, iters=it, rows=rows, lam=lam,
-               hist=hist, rp=rp, rd=rd, rho=rho, Q=Q, Vt=Vt,
+               hist=hist, rp=rp, rd=rd, rho=rho, Q=Q, Vt=Vt, n_aa=n_aa, n_aa_rejected=n_aa_rej,
                warm=dict(Y=Y, U=Q @ Vt, Yp=Yp, alpha=alpha, svals=svals, D1=D1, D3=D3, rho=rho))
     if want_certificate:
         # Theta = X' pinv(Y) X = gamma * Lam' X is the minimal Theta with [Y X; X' Theta] >= 0

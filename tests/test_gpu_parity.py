@@ -3,11 +3,13 @@ checker is the CPU oracle on the same seeded inputs.  Tolerances: the relaxation
 relative (both sides certify their value within 1e-6 of the optimum of the convex program); plain kernels
 (objective scan, eigen-oracle) at 1e-12 / 1e-8."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 GAMMA = 80.0
 OBJ_REL = 2e-6
 
@@ -338,4 +340,28 @@ def test_shor_counts_config3_size(have_gpu, omc, orc):
     order = np.lexsort((key, sc))[::-1][:100]
     assert [t for _, t in top] == [tuple(int(v) for v in T[i]) for i in order]
     assert [s for s, _ in top] == [float(sc[i]) for i in order]
+    eng.close()
+
+
+def test_anderson_acceleration_option(have_gpu, omc, orc):
+    """accel = 1 (k_aa): same certified optimum as the plain iteration, far fewer iterations on the crawling node of the
+    README fixture (node L = 2: SLOW_PROGRESS at 3000 iterations without, OPTIMAL with), and the same trajectory as the
+    oracle's mirror of the scheme on these small cases."""
+    z = np.load(os.path.join(HERE, "golden", "readme_20x24_k1_linear.npz"), allow_pickle=False)
+    DN = {0: "left", 1: "middle", 2: "right", 3: "inner_left", 4: "inner_right"}
+    cuts = [(z["cut_x"][l], z["cut_U"][l], [DN[int(c)] for c in z["cut_dir"][l]]) for l in range(len(z["cut_x"]))]
+    nodes = [cuts[:int(L)] for L in z["node_L"]]
+    eng = omc.Engine(z["A"], z["mask"], 80.0, 1)
+    plain = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=omc.default_params(rho_scale=16.0, accel=0))
+    fast = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=omc.default_params(rho_scale=16.0, accel=1))
+    inst = orc.Instance(z["A"], z["mask"], 80.0, 1)
+    assert plain[2]["status_code"] == 1 and fast[2]["status_code"] == 0 and fast[2]["iters"] < 500
+    for b, (p_, f_) in enumerate(zip(plain, fast)):
+        assert f_["status_code"] == 0 and f_["iters"] <= p_["iters"]
+        assert f_["objective"] == pytest.approx(p_["objective"], rel=OBJ_REL)
+        assert f_["objective"] - f_["dual_bound"] <= 1.01e-6 * max(1.0, abs(f_["objective"]))
+        assert f_["dual_bound"] <= p_["objective"] * (1 + 1e-7)
+        r = orc.sdp_relaxation(inst, nodes[b], "linear", params=orc.RelaxParams(rho_scale=16.0, accel=1), want_certificate=False)
+        assert r["termination_status"] == 0 and abs(r["iters"] - f_["iters"]) <= 25
+        assert f_["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
     eng.close()
