@@ -31,8 +31,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--depth", type=int, default=int(os.environ.get("OMC_BENCH_DEPTH", 9)), help="frontier depth: 2^depth nodes per GPU per step")
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("OMC_BENCH_SLOTS", 256)), help="nodes relaxed concurrently per GPU (continuous batching)")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("OMC_BENCH_DEPTH", 11)), help="frontier depth: 2^depth nodes per GPU per step")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("OMC_BENCH_SLOTS", 2048)), help="nodes relaxed concurrently per GPU (continuous batching)")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--cpu-nodes", type=int, default=2, help="nodes relaxed by the CPU oracle for cpu_baseline (rank 0, N=1 only)")
     args = ap.parse_args()

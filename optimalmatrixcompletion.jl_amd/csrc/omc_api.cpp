@@ -59,6 +59,10 @@ struct omc_instance {
   std::vector<int> row_ptr, row_idx; std::vector<double> row_val;
   DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG;
   hipStream_t stream = nullptr;
+  // per slot group: main / column / small-cone streams and fork, join, done events (see omc_relax_solve)
+  hipStream_t gs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  hipEvent_t gev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  hipEvent_t ev_main = nullptr;
   DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY;
   // batch workspace
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
@@ -196,6 +200,11 @@ void omc_instance_destroy(omc_instance* h) {
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (int g = 0; g < 2; ++g) {
+    for (int q = 0; q < 3; ++q) if (h->gs[g][q]) (void)hipStreamDestroy(h->gs[g][q]);
+    for (int q = 0; q < 4; ++q) if (h->gev[g][q]) (void)hipEventDestroy(h->gev[g][q]);
+  }
+  if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   delete h;
 }
 
@@ -228,15 +237,16 @@ static hipEvent_t next_event(omc_instance* h) {
   }
   return h->ev_pool[h->ev_used++];
 }
-#define TIMED(cls, units_, call)                     \
+#define TIMED_ON(strm, cls, units_, call)             \
   do {                                               \
     hipEvent_t e0_ = next_event(h), e1_ = next_event(h); \
-    (void)hipEventRecord(e0_, h->stream);            \
+    (void)hipEventRecord(e0_, strm);                 \
     call;                                            \
-    (void)hipEventRecord(e1_, h->stream);            \
+    (void)hipEventRecord(e1_, strm);                 \
     h->ev_class.push_back(cls);                      \
     h->launches[cls] += 1; h->units[cls] += (units_); \
   } while (0)
+#define TIMED(cls, units_, call) TIMED_ON(h->stream, cls, units_, call)
 
 int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
                     const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
@@ -356,6 +366,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   int S = (P.slots > 0) ? std::min(P.slots, B) : std::min(B, 256);
   if (getenv("OMC_SLOTS")) S = std::max(1, std::min(B, atoi(getenv("OMC_SLOTS"))));
   h->Btot = B;
+  w.b0 = 0; w.nB = S;
   w.B = S; w.Btot = B; w.max_iters = P.max_iters; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
   w.jacobi_tau = getenv("OMC_JACOBI_TAU") ? atof(getenv("OMC_JACOBI_TAU")) : 0.0;
   w.max_sweeps = getenv("OMC_DEBUG_MAX_SWEEPS") ? atoi(getenv("OMC_DEBUG_MAX_SWEEPS")) : 30;
@@ -586,19 +597,55 @@ int omc_relax_solve(omc_instance* h) {
   TIMED(OMC_KERNEL_SETUP, S, omc_launch_setup(&w, s));
   int it = 0;
   const int check = std::max(1, P.check_every);
+  // Streams.  Inside an iteration the three blocks are independent of each other (columns: Y, Yp, alpha -> alpha, Lambda;
+  // cone: Y - D1 -> W1; small cone: Y, D3, V -> E3, W3*): a main stream (cone, then the global step) and two side streams
+  // (columns, small cone) forked and joined by events, so that the latency-bound column waves and the small workgroups
+  // share the CUs with the LDS-bound cone kernel (measured on config 2, 2048 slots: 212 -> 235 node-relaxations/s).
+  // OMC_STREAMS=1 serialises everything on one stream (kernel-by-kernel measurements).  OMC_GROUPS=2 additionally splits
+  // the slots in two groups with their own stream triple, meeting only at the certificate checks, so that one group's
+  // global step overlaps the other's cone kernel: measured slower (219/s), kept for experiments only.
+  const bool multi = !(getenv("OMC_STREAMS") && atoi(getenv("OMC_STREAMS")) <= 1);
+  const int G = (multi && S >= 64 && getenv("OMC_GROUPS") && atoi(getenv("OMC_GROUPS")) == 2) ? 2 : 1;
+  if (multi && !h->ev_main) {
+    for (int g = 0; g < 2; ++g) {
+      for (int q = 0; q < 3; ++q) HIPCHK(hipStreamCreateWithFlags(&h->gs[g][q], hipStreamNonBlocking));
+      for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreateWithFlags(&h->gev[g][q], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+  }
+  int gb0[2] = {0, 0}, gnB[2] = {S, 0}, gact[2] = {S, 0};
+  if (G == 2) { gnB[0] = S / 2; gb0[1] = S / 2; gnB[1] = S - S / 2; gact[0] = gnB[0]; gact[1] = gnB[1]; }
   bool timed_out = false;
   h->total_sweeps = 0;
+  bool wait_main = true;     // group streams must wait for the work queued on the main stream (setup, checks, refills)
   while (nactive > 0) {
     ++it;
-    TIMED(OMC_KERNEL_COLPROX, (int64_t)nactive * w.m, omc_launch_colprox(&w, 0, s));
-    if (h->ws_lpp) TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone_ws(&w, h->ws_lpp, h->ws_use_lds, h->ws_lds, s));
-    else TIMED(OMC_KERNEL_CONE, nactive, omc_launch_cone(&w, CONE_CLIP01, h->cone_use_lds, h->cone_lds, s));
-    TIMED(OMC_KERNEL_SMALL, nactive, omc_launch_small(&w, SMALL_PROJ, h->small_use_lds, h->small_lds, s));
-    TIMED(OMC_KERNEL_GLOBAL, nactive, omc_launch_global(&w, h->glob_use_lds, h->glob_lds, s));
-    if (it % check != 0) {
-      if (w.accel) TIMED(OMC_KERNEL_ACCEL, nactive, omc_launch_aa(&w, s));
-      continue;
+    const bool is_check = (it % check == 0);
+    if (multi && wait_main) HIPCHK(hipEventRecord(h->ev_main, s));
+    for (int g = 0; g < G; ++g) {
+      if (gact[g] == 0) continue;
+      OmcWS wg = w; wg.b0 = gb0[g]; wg.nB = gnB[g];
+      hipStream_t sm = multi ? h->gs[g][0] : s, sb = multi ? h->gs[g][1] : s, sc = multi ? h->gs[g][2] : s;
+      if (multi) {
+        if (wait_main) HIPCHK(hipStreamWaitEvent(sm, h->ev_main, 0));
+        HIPCHK(hipEventRecord(h->gev[g][0], sm));
+        HIPCHK(hipStreamWaitEvent(sb, h->gev[g][0], 0)); HIPCHK(hipStreamWaitEvent(sc, h->gev[g][0], 0));
+      }
+      TIMED_ON(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
+      if (h->ws_lpp) TIMED_ON(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
+      else TIMED_ON(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone(&wg, CONE_CLIP01, h->cone_use_lds, h->cone_lds, sm));
+      TIMED_ON(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
+      if (multi) {
+        HIPCHK(hipEventRecord(h->gev[g][1], sb)); HIPCHK(hipEventRecord(h->gev[g][2], sc));
+        HIPCHK(hipStreamWaitEvent(sm, h->gev[g][1], 0)); HIPCHK(hipStreamWaitEvent(sm, h->gev[g][2], 0));
+      }
+      TIMED_ON(sm, OMC_KERNEL_GLOBAL, gact[g], omc_launch_global(&wg, h->glob_use_lds, h->glob_lds, sm));
+      if (!is_check && w.accel) TIMED_ON(sm, OMC_KERNEL_ACCEL, gact[g], omc_launch_aa(&wg, sm));
+      if (multi && is_check) { HIPCHK(hipEventRecord(h->gev[g][3], sm)); HIPCHK(hipStreamWaitEvent(s, h->gev[g][3], 0)); }
     }
+    wait_main = false;
+    if (!is_check) continue;
+    wait_main = true;
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     timed_out = el > P.time_limit;
     TIMED(OMC_KERNEL_CHECK, nactive, {
@@ -634,8 +681,8 @@ int omc_relax_solve(omc_instance* h) {
       rc = push_flags(init, fin); if (rc) return rc;
       if (ninit) TIMED(OMC_KERNEL_SETUP, ninit, omc_launch_setup(&w, s));
     }
-    nactive = 0;
-    for (int b = 0; b < S; ++b) nactive += node_of[b] >= 0 ? 1 : 0;
+    nactive = 0; gact[0] = gact[1] = 0;
+    for (int b = 0; b < S; ++b) if (node_of[b] >= 0) { ++nactive; ++gact[(G == 2 && b >= gb0[1]) ? 1 : 0]; }
     if (timed_out && next < Btot) {
       // nodes that never got a slot: report TIME_LIMIT without values
       std::vector<int> st(Btot - next, OMC_ST_TIME), itz(Btot - next, 0);

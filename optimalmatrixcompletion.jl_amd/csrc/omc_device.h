@@ -28,6 +28,7 @@ struct OmcWS {
   // sizes
   // B = number of SLOTS (state arrays, grid size); Btot = number of nodes of the staged batch (descriptor and output arrays).
   // node_of[b] = node currently relaxed in slot b.
+  int b0, nB;   // slot range [b0, b0 + nB) handled by a launch of the per-iteration kernels (the slots are split in groups that run on their own streams)
   int B, Btot, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16, max_sweeps, max_iters;
   int *node_of, *init, *fin;   // B
   const double* rho_node;      // Btot: initial penalty of each node

@@ -399,15 +399,15 @@ __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   extern __shared__ double smem[];
   const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const int gw = blockIdx.x * wpb + wave_in_blk;  // global wave id
-  const int b = gw / w.m, j = gw - b * w.m;
-  if (b >= w.B) return;
+  const int bl = gw / w.m, j = gw - bl * w.m, b = bl + w.b0;
+  if (bl >= w.nB) return;
   if (w.done[b]) return;
   const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
   if (c == 0) return;
   DIAG_T0();
   // two inlined copies so that the LDS copy compiles to ds_read/ds_write (not flat) instructions
   if (c <= w.cp_lds_c) colprox_reg(w, mode, b, j, off, c, lane, smem + (size_t)wave_in_blk * w.cp_lds_doubles);   // cp_lds_c <= 64
-  else colprox_body(w, mode, b, j, off, c, lane, w.cp_scratch + (size_t)gw * w.cp_scratch_stride);
+  else colprox_body(w, mode, b, j, off, c, lane, w.cp_scratch + ((size_t)b * w.m + j) * w.cp_scratch_stride);
   if (lane == 0 && mode == 0) DIAG_CYC(0, b);
 }
 
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
   __shared__ int s_cnt;
   __shared__ int s_nsel;
   __shared__ double s_base;
-  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] && mode != CONE_SEP && mode != CONE_TOPK) return;
   if ((mode == CONE_SEP || mode == CONE_TOPK) && !w.fin[b]) return;
   const int n = w.n, k = w.k;
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   extern __shared__ double smem[];
   __shared__ int s_nsel;
   __shared__ double s_base;
-  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
   const int n = w.n, N = n, NP = w.np16;
   const int Np = (N + 1) & ~1;
@@ -964,7 +964,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   __shared__ double red[32];
   __shared__ int s_cnt, s_nsel;
   __shared__ double s_base;
-  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] && mode == SMALL_PROJ) return;
   if (mode == SMALL_RECOVER && !w.fin[b]) return;   // recovery runs once, when the slot's node is harvested
   const int nb = w.node_of[b];
@@ -1116,7 +1116,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   __shared__ double s_Gp[NNQP_PMAX * (NNQP_PMAX + 1) / 2];
   __shared__ double s_sv[NNQP_PMAX], s_tmp[NNQP_PMAX];
   __shared__ int s_pl[NNQP_PMAX];
-  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
   const int nb = w.node_of[b];
   const int n = w.n, k = w.k, m = w.m, rm = w.rmax;
@@ -1450,7 +1450,7 @@ __global__ void __launch_bounds__(512) k_aa(OmcWS w) {
   __shared__ double red[32];
   __shared__ double s_H[AA_MAXMEM * AA_MAXMEM], s_rhs[AA_MAXMEM], s_gam[AA_MAXMEM];
   __shared__ int s_ok;
-  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
   const int it = w.iters[b];
   if (it < w.aa_start - 1) return;
@@ -1682,25 +1682,25 @@ __global__ void __launch_bounds__(256) k_eval_objective(int n, int m, double gam
 template <int LPP>
 static void launch_ws_lds(const OmcWS* w, int rpl2, size_t lds_bytes, hipStream_t s) {
   switch (rpl2) {   // straight-line (branch-free) row loops for the common sizes, run-time bound otherwise
-    case 4: hipLaunchKernelGGL((k_cone_ws<LPP, true, 4>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
-    case 5: hipLaunchKernelGGL((k_cone_ws<LPP, true, 5>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
-    case 6: hipLaunchKernelGGL((k_cone_ws<LPP, true, 6>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
-    case 7: hipLaunchKernelGGL((k_cone_ws<LPP, true, 7>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
-    case 8: hipLaunchKernelGGL((k_cone_ws<LPP, true, 8>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
-    default: hipLaunchKernelGGL((k_cone_ws<LPP, true, 0>), dim3(w->B), dim3(512), lds_bytes, s, *w); break;
+    case 4: hipLaunchKernelGGL((k_cone_ws<LPP, true, 4>), dim3(w->nB), dim3(512), lds_bytes, s, *w); break;
+    case 5: hipLaunchKernelGGL((k_cone_ws<LPP, true, 5>), dim3(w->nB), dim3(512), lds_bytes, s, *w); break;
+    case 6: hipLaunchKernelGGL((k_cone_ws<LPP, true, 6>), dim3(w->nB), dim3(512), lds_bytes, s, *w); break;
+    case 7: hipLaunchKernelGGL((k_cone_ws<LPP, true, 7>), dim3(w->nB), dim3(512), lds_bytes, s, *w); break;
+    case 8: hipLaunchKernelGGL((k_cone_ws<LPP, true, 8>), dim3(w->nB), dim3(512), lds_bytes, s, *w); break;
+    default: hipLaunchKernelGGL((k_cone_ws<LPP, true, 0>), dim3(w->nB), dim3(512), lds_bytes, s, *w); break;
   }
 }
 extern "C" {
 void omc_launch_setup(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s) {
   const int wpb = 4;
-  const int waves = w->B * w->m;
+  const int waves = w->nB * w->m;
   const int blocks = (waves + wpb - 1) / wpb;
   hipLaunchKernelGGL(k_colprox, dim3(blocks), dim3(wpb * 64), (size_t)wpb * w->cp_lds_doubles * sizeof(double), s, *w, mode);
 }
 void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
-  if (use_lds) hipLaunchKernelGGL(k_cone<true>, dim3(w->B), dim3(512), lds_bytes, s, *w, mode);
-  else hipLaunchKernelGGL(k_cone<false>, dim3(w->B), dim3(512), 0, s, *w, mode);
+  if (use_lds) hipLaunchKernelGGL(k_cone<true>, dim3(w->nB), dim3(512), lds_bytes, s, *w, mode);
+  else hipLaunchKernelGGL(k_cone<false>, dim3(w->nB), dim3(512), 0, s, *w, mode);
 }
 void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, hipStream_t s) {
   const int rpl2 = ((((w->n + lpp - 1) / lpp) + 1) & ~1) >> 1;
@@ -1709,16 +1709,16 @@ void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, 
     else if (lpp == 8) launch_ws_lds<8>(w, rpl2, lds_bytes, s);
     else launch_ws_lds<4>(w, rpl2, lds_bytes, s);
   } else {
-    hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->B), dim3(512), 0, s, *w);
+    hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->nB), dim3(512), 0, s, *w);
   }
 }
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
-  if (use_lds) hipLaunchKernelGGL(k_small<true>, dim3(w->B), dim3(256), lds_bytes, s, *w, mode);
-  else hipLaunchKernelGGL(k_small<false>, dim3(w->B), dim3(256), 0, s, *w, mode);
+  if (use_lds) hipLaunchKernelGGL(k_small<true>, dim3(w->nB), dim3(256), lds_bytes, s, *w, mode);
+  else hipLaunchKernelGGL(k_small<false>, dim3(w->nB), dim3(256), 0, s, *w, mode);
 }
 void omc_launch_global(const OmcWS* w, int use_lds, size_t lds_bytes, hipStream_t s) {
-  if (use_lds) hipLaunchKernelGGL(k_global<true>, dim3(w->B), dim3(512), lds_bytes, s, *w);
-  else hipLaunchKernelGGL(k_global<false>, dim3(w->B), dim3(512), 0, s, *w);
+  if (use_lds) hipLaunchKernelGGL(k_global<true>, dim3(w->nB), dim3(512), lds_bytes, s, *w);
+  else hipLaunchKernelGGL(k_global<false>, dim3(w->nB), dim3(512), 0, s, *w);
 }
 void omc_launch_check_zero(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_zero_check, dim3((w->B + 63) / 64), dim3(64), 0, s, *w); }
 void omc_launch_check_build(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_check_build, dim3(w->B), dim3(512), 0, s, *w); }
@@ -1727,7 +1727,7 @@ void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s) {
 }
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_rho_rescale, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_harvest(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_harvest, dim3(w->B), dim3(256), 0, s, *w); }
-void omc_launch_aa(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_aa, dim3(w->B), dim3(512), 0, s, *w); }
+void omc_launch_aa(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_aa, dim3(w->nB), dim3(512), 0, s, *w); }
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s) { hipLaunchKernelGGL(k_make_X, dim3(64, w->Btot), dim3(256), 0, s, *w, X); }
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s) {
   hipLaunchKernelGGL(k_make_Theta, dim3(64, w->Btot), dim3(256), 0, s, *w, X, Th);
