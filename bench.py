@@ -96,6 +96,8 @@ def main():
     achieved = f_proj(n) * mats_per_launch / (avg_ms * 1e-3) / 1e12
     roofline = dict(bound="mfma", kernel="k_cone", achieved=achieved, peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / F64_PEAK_TFLOPS,
                     traffic=None, avg_launch_ms=avg_ms, matrices_per_launch=mats_per_launch, order=n,
+                    concurrency="k_cone_ws shares the CUs with k_colprox and k_small of the same iteration (three HIP streams), so its launch "
+                                "duration includes that sharing; OMC_STREAMS=1 runs the kernels back to back (DESIGN.md 5.1 has both)",
                     kernel_ms={c: round(v["ms"], 2) for c, v in kstats.items()})
 
     cpu_baseline = None
