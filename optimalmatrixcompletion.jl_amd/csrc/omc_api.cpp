@@ -527,7 +527,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
           w.cone_scratch = h->bcone.as<double>();
         }
       }
-      h->ws_lpp = (rpl <= 20 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
+      h->ws_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;   // WS_JROWS
     }
     h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8 + (size_t)h->nnz * 4 + 16;   // n*m >= n*n: the region also stages Lambda
     h->glob_use_lds = h->glob_lds + 12 * 1024 <= OMC_MAX_DYN_LDS;

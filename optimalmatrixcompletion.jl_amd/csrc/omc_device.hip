@@ -423,6 +423,7 @@ __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
 //   mode CONE_SEP   : M = U U' - Y               -> two smallest eigenpairs -> lmin[2b..], bx
 // ---------------------------------------------------------------------------------------------------------
 #define JROWS 20  // rows cached in registers per lane
+#define WS_JROWS 32  // same for the warm-started kernel's run-time-bound variant (n <= 16 * 32 = 512)
 
 __device__ __forceinline__ void rr_pair(int step, int t, int Np, int& p, int& q) {
   // round-robin tournament on Np (even) players: step in [0,Np-1), t in [0,Np/2)
@@ -858,7 +859,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
           auto gp = (double2v*)(Gm + (size_t)p * ld + lg * rpl);
           auto gq = (double2v*)(Gm + (size_t)q * ld + lg * rpl);
           const int rpl2 = rpl >> 1;
-          constexpr int R2 = RPL2 ? RPL2 : JROWS / 2;
+          constexpr int R2 = RPL2 ? RPL2 : WS_JROWS / 2;
           double2v cp_[R2], cq_[R2];
           double gm0 = 0.0, gm1 = 0.0;
 #pragma unroll

@@ -365,3 +365,26 @@ def test_anderson_acceleration_option(have_gpu, omc, orc):
         assert r["termination_status"] == 0 and abs(r["iters"] - f_["iters"]) <= 25
         assert f_["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
     eng.close()
+
+
+def test_branch_and_bound_invariants(have_gpu, omc, orc):
+    """Driver counterpart (bnb.branch_and_bound) on the README-type 20 x 24 instance: the per-run invariants of SURVEY 8c --
+    LB monotone, LB <= UB, counter identity (OMC.jl:411-425), incumbent = evaluate_objective(X) of a rank-k X, and a root
+    bound that the oracle confirms."""
+    A, mask = orc.make_instance(20, 24, 1, seed=11, kind="readme")
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    sol, inst = omc.pkg.bnb.branch_and_bound(eng, A, mask, gap=1e-3, time_limit=60.0, batch=16, rho_scale=16.0, use_max_steps=True, max_steps=150)
+    log = np.array(inst["run_log"]); c = inst["run_details"]
+    assert len(log) >= 2
+    lbs, ubs = log[:, 3], log[:, 4]
+    assert (np.diff(lbs) >= -1e-9).all() and (np.diff(ubs) <= 1e-12).all()            # OMC.jl:1213-1216; incumbent only improves
+    assert (lbs <= ubs * (1 + 1e-9)).all() and sol["lower_bound"] <= sol["objective"] * (1 + 1e-9)
+    assert c["nodes_dominated"] + c["nodes_relax_infeasible"] + c["nodes_relax_feasible"] == c["nodes_explored"]
+    assert c["nodes_relax_feasible"] >= c["nodes_relax_feasible_pruned"] + c["nodes_master_feasible"] + c["nodes_relax_feasible_split"]
+    assert np.linalg.matrix_rank(sol["X"], tol=1e-8) <= 1
+    assert sol["objective"] == pytest.approx(orc.evaluate_objective(sol["X"], A, mask, GAMMA), rel=1e-10)
+    inst_o = orc.Instance(A, mask, GAMMA, 1)
+    root = orc.sdp_relaxation(inst_o, params=orc.RelaxParams(rho_scale=16.0), want_certificate=False)
+    assert log[0, 3] == pytest.approx(root["dual_bound"], rel=2e-6)                   # first logged LB = certified root bound
+    assert root["dual_bound"] <= sol["objective"] * (1 + 1e-9)
+    eng.close()
