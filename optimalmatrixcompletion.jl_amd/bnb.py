@@ -140,8 +140,11 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     Us, _, _ = np.linalg.svd(X0, full_matrices=False)
     U_init = Us[:, :k]
     ub = float(engine.evaluate_objective(X0))
-    solution.update(objective_initial=ub, X_initial=X0, U_initial=U_init, Y_initial=U_init @ U_init.T,
-                    objective=ub, X=X0, U=U_init, Y=U_init @ U_init.T, objective_time_found=time.time() - start)
+    from .data import compute_MSE
+    mse0 = {kind: compute_MSE(X0, A, indices, kind) for kind in ("in", "out", "all")}                 # OMC.jl:570-572
+    solution.update(objective_initial=ub, objective_initial_time_found=time.time() - start, X_initial=X0, U_initial=U_init,
+                    Y_initial=U_init @ U_init.T, MSE_in_initial=mse0["in"], MSE_out_initial=mse0["out"], MSE_all_initial=mse0["all"],
+                    objective=ub, X=X0, U=U_init, Y=U_init @ U_init.T, objective_time_found=time.time() - start)   # OMC.jl:604-621
     if rho_scale is None:
         rho_scale, _ = autotune_rho_scale(engine, disjunctive_cuts_type)
     P = params or default_params(rho_scale=float(rho_scale), breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints])
@@ -275,7 +278,10 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
         if root_only:
             break
     elapsed = time.time() - start
-    solution.update(lower_bound=lb, gap=now_gap)
-    instance = dict(run_log=run_log, run_details=dict(counters, time_taken=elapsed, solve_time_relaxation=t_relax, solve_time_altmin=t_altmin,
+    solution.update(lower_bound=lb, gap=now_gap, MSE_in=compute_MSE(solution["X"], A, indices, "in"),
+                    MSE_out=compute_MSE(solution["X"], A, indices, "out"), MSE_all=compute_MSE(solution["X"], A, indices, "all"))   # OMC.jl:1079-1081
+    # run_log columns as the reference's DataFrame (OMC.jl:457-465): explored, total, remaining, lower, upper, gap, runtime
+    instance = dict(run_log=run_log, run_log_columns=("explored", "total", "remaining", "lower", "upper", "gap", "runtime"),
+                    run_details=dict(counters, time_taken=elapsed, solve_time_relaxation=t_relax, solve_time_altmin=t_altmin,
                                                       rho_scale=float(rho_scale), batch=batch, n=n, m=m, k=k))
     return solution, instance

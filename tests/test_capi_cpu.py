@@ -79,3 +79,24 @@ def test_host_side_helpers(omc):
     x = np.arange(4.0); U = np.ones((4, 1))
     kids = bnb.make_children([("c0",)], dict(breakpoint_vec=x, U=U), "linear", 1)
     assert len(kids) == 2 and kids[0][0] == ("c0",) and kids[1][-1][2] == ["right"]
+
+
+def test_instance_and_node_log_round_trip(omc, tmp_path):
+    """On-disk formats: instance directory (A.npy, Julia-BitMatrix mask chunks, JSON) and node replay log."""
+    data = omc.pkg.data
+    A, mask = data.generate_matrix_completion_data(1, 9, 13, 60, seed=3)
+    info = data.save_instance(str(tmp_path / "inst"), A, mask, 80.0, 1, meta={"config": "test"})
+    A2, mask2, info2 = data.load_instance(str(tmp_path / "inst"))
+    assert np.array_equal(A, A2) and np.array_equal(mask, mask2) and info2["sha256"] == info["sha256"] and info2["n_indices"] == 60
+    chunks = data.pack_mask_bits(mask)
+    assert chunks.dtype == np.uint64 and len(chunks) == (9 * 13 + 63) // 64
+    assert all(bool((int(chunks[e // 64]) >> (e % 64)) & 1) == bool(mask[e % 9, e // 9]) for e in range(9 * 13))   # column-major, LSB first
+    rng = np.random.default_rng(0)
+    nodes = [[], [(rng.standard_normal(9), rng.standard_normal((9, 1)), ["left"])],
+             [(rng.standard_normal(9), rng.standard_normal((9, 1)), ["right"]), (rng.standard_normal(9), rng.standard_normal((9, 1)), ["left"])]]
+    data.save_nodes(str(tmp_path / "nodes.npz"), nodes, 9, 1)
+    back = data.load_nodes(str(tmp_path / "nodes.npz"))
+    assert [len(c) for c in back] == [0, 1, 2] and back[2][1][2] == ["left"] and np.array_equal(back[2][0][0], nodes[2][0][0])
+    assert data.compute_MSE(A, A, mask, "all") == 0.0
+    with pytest.raises(ValueError):
+        data.compute_MSE(A, A, mask, "bogus")
