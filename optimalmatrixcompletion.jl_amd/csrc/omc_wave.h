@@ -124,7 +124,7 @@ __device__ __forceinline__ bool wave_ldl(PT Lm, PT pinv, int c, int r, int g, in
   for (int kk = 0; kk < c; ++kk) {
     WAVE_SYNC();
     const double piv = Lm[tri_i(kk, kk)];
-    if (!(piv > 0.0)) return false;
+    if (!(piv > 1e-290)) return false;      // not positive definite (also keeps fast_rcp in its normal range)
     const double pi_ = fast_rcp(piv);
     if (lane == 0) pinv[kk] = pi_;
     if (r > kk && r < c) {
