@@ -138,8 +138,9 @@ int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int*
                     double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x,
                     double* solve_time);
 
-/* ---- alternating_minimization (OMC.jl:1979-2279), disjunctive mode, B problems at once -----------------
- * U_initial n*k per problem; cuts as above (only the per-cut bounds on v = U'x are imposed, OMC.jl:2047-2093).
+/* ---- alternating_minimization (OMC.jl:1979-2279), disjunctive mode, B problems at once, rank k <= 4 --------
+ * U_initial n*k per problem; cuts as above (only the per-cut bounds on v = U'x are imposed, OMC.jl:2047-2093);
+ * k > 1 adds the pair cones ||U_j1 +- U_j2|| <= sqrt 2 of OMC.jl:2029-2045.
  * Outputs: U n*k, V k*m, converged, n_iters, objectives (max_iters doubles per problem, NaN padded).     */
 int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q1, const int* L,
                      const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_initial,

@@ -118,8 +118,8 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     if node_selection not in ("breadthfirst", "bestfirst", "depthfirst", "bestfirst_depthfirst"):
         raise ValueError("Invalid input for node selection.")                              # OMC.jl:233-238
     n, m, k = engine.n, engine.m, engine.k
-    if engine.k != 1 and altmin_flag:
-        raise NotImplementedError("GPU altmin is rank-1 in this round; pass altmin_flag=False for k > 1")
+    if engine.k > 4 and altmin_flag:
+        raise NotImplementedError("GPU altmin supports rank k <= 4; pass altmin_flag=False beyond that")
     rng = np.random.default_rng(seed)                                                      # OMC.jl:333 (Random.seed!(0))
     start = time.time()
     counters = dict(nodes_explored=0, nodes_total=1, nodes_dominated=0, nodes_relax_infeasible=0, nodes_relax_feasible=0,

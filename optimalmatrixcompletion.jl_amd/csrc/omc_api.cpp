@@ -57,7 +57,7 @@ struct omc_instance {
   std::vector<double> A; std::vector<uint8_t> mask;
   std::vector<double> Ncnt;
   std::vector<int> row_ptr, row_idx; std::vector<double> row_val;
-  DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG;
+  DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arbj, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG;
   hipStream_t stream = nullptr;
   // per slot group: main / column / small-cone streams and fork, join, done events (see omc_relax_solve)
   hipStream_t gs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -194,7 +194,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
-                   &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arcoef, &h->arrhs, &h->acutx,
+                   &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
                    &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
   for (DevBuf* b : all) b->release();
@@ -820,37 +820,41 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   if (B <= 0 || max_iters <= 0) return fail(OMC_ERR_ARGUMENT, "B and max_iters must be positive");
   if (cut_type != OMC_CUT_LINEAR && cut_type != OMC_CUT_LINEAR2 && cut_type != OMC_CUT_LINEAR3)
     return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type (OMC.jl:1456-1462)");
-  if (h->k != 1) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: rank k > 1 is not built yet (the oracle covers it)");
+  if (h->k > 4) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: rank k > 4 is not supported");
   HIPCHK(hipSetDevice(h->device));
-  const int n = h->n, m = h->m;
+  const int n = h->n, m = h->m, k = h->k;
   auto t0 = std::chrono::steady_clock::now();
   int Lmax = 1; long Ltot = 0;
   for (int b = 0; b < B; ++b) { int Lb = L ? L[b] : 0; if (Lb < 0) return fail(OMC_ERR_ARGUMENT, "negative cut count"); Lmax = std::max(Lmax, Lb); Ltot += Lb; }
   if (Ltot > 0 && (!cut_x || !cut_Uhat || !cut_dir)) return fail(OMC_ERR_ARGUMENT, "cut arrays are NULL but L > 0");
-  // rows of model_U: box entries not implied by ||u|| <= 1 (defaults OMC.jl:1989-1996: u_n >= 0), per-cut bounds (2047-2093)
-  const int Rmax = 1 + 2 * Lmax;
+  // rows of model_U: box entries not implied by ||U_j|| <= 1 (defaults OMC.jl:1989-1996: U[n-k+j.., j] >= 0), per-cut bounds on
+  // every column (2047-2093)
+  const int Rmax = k * (k + 1) / 2 + 2 * k * Lmax;
   const size_t sB = (size_t)B;
-  std::vector<int> hR(B, 0), hk(sB * Rmax, 0), hc(sB * Rmax, 0), hbi(sB * Rmax, 0);
+  std::vector<int> hR(B, 0), hk(sB * Rmax, 0), hc(sB * Rmax, 0), hbi(sB * Rmax, 0), hbj(sB * Rmax, 0);
   std::vector<double> hcoef(sB * Rmax, 0.0), hrhs(sB * Rmax, 0.0), hx(sB * Lmax * n, 0.0);
   long cutbase = 0;
   for (int b = 0; b < B; ++b) {
     int r = 0;
-    auto add = [&](int kind, int cut, int bi, double cf, double rhs) {
-      hk[(size_t)b * Rmax + r] = kind; hc[(size_t)b * Rmax + r] = cut; hbi[(size_t)b * Rmax + r] = bi;
+    auto add = [&](int kind, int cut, int bi, int bj, double cf, double rhs) {
+      hk[(size_t)b * Rmax + r] = kind; hc[(size_t)b * Rmax + r] = cut; hbi[(size_t)b * Rmax + r] = bi; hbj[(size_t)b * Rmax + r] = bj;
       hcoef[(size_t)b * Rmax + r] = cf; hrhs[(size_t)b * Rmax + r] = rhs; ++r;
     };
-    add(ROW_BOX, -1, n - 1, -1.0, 0.0);                      // -u_n <= 0  (symmetry breaking, OMC.jl:1991-1993)
+    for (int j = 0; j < k; ++j)
+      for (int i = n - k + j; i < n; ++i) add(ROW_BOX, -1, i, j, -1.0, 0.0);     // -U[i,j] <= 0  (symmetry breaking, OMC.jl:1991-1993)
     const int Lb = L ? L[b] : 0;
     for (int l = 0; l < Lb; ++l) {
       const double* x = cut_x + (size_t)(cutbase + l) * n;
-      const double* Uh = cut_Uhat + (size_t)(cutbase + l) * n;
-      double vhat = 0.0;
-      for (int i = 0; i < n; ++i) vhat += Uh[i] * x[i];      // OMC.jl:2053
-      double lo, hi, sl, ic;
-      if (cut_piece(cut_type, cut_dir[cutbase + l], vhat, reference_quirk_q1, &lo, &hi, &sl, &ic))
-        return fail(OMC_ERR_INVALID_ENUM, "direction code invalid for this cut type (OMC.jl:2056-2091)");
-      add(ROW_BOUND, l, -1, 1.0, hi);
-      add(ROW_BOUND, l, -1, -1.0, -lo);
+      for (int j = 0; j < k; ++j) {
+        const double* Uh = cut_Uhat + ((size_t)(cutbase + l) * k + j) * n;
+        double vhat = 0.0;
+        for (int i = 0; i < n; ++i) vhat += Uh[i] * x[i];      // OMC.jl:2053
+        double lo, hi, sl, ic;
+        if (cut_piece(cut_type, cut_dir[(size_t)(cutbase + l) * k + j], vhat, reference_quirk_q1, &lo, &hi, &sl, &ic))
+          return fail(OMC_ERR_INVALID_ENUM, "direction code invalid for this cut type (OMC.jl:2056-2091)");
+        add(ROW_BOUND, l, -1, j, 1.0, hi);
+        add(ROW_BOUND, l, -1, j, -1.0, -lo);
+      }
       memcpy(&hx[((size_t)b * Lmax + l) * n], x, sizeof(double) * n);
     }
     hR[b] = r; cutbase += Lb;
@@ -861,29 +865,31 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   if ((rc_ = upload(h->arkind, hk.data(), sizeof(int) * hk.size(), s))) return rc_;
   if ((rc_ = upload(h->arcut, hc.data(), sizeof(int) * hc.size(), s))) return rc_;
   if ((rc_ = upload(h->arbi, hbi.data(), sizeof(int) * hbi.size(), s))) return rc_;
+  if ((rc_ = upload(h->arbj, hbj.data(), sizeof(int) * hbj.size(), s))) return rc_;
   if ((rc_ = upload(h->arcoef, hcoef.data(), sizeof(double) * hcoef.size(), s))) return rc_;
   if ((rc_ = upload(h->arrhs, hrhs.data(), sizeof(double) * hrhs.size(), s))) return rc_;
   if ((rc_ = upload(h->acutx, hx.data(), sizeof(double) * hx.size(), s))) return rc_;
-  if ((rc_ = upload(h->aU0, U_initial, sizeof(double) * sB * n, s))) return rc_;
-  if ((rc_ = h->aU.ensure(8 * sB * n))) return rc_;
-  if ((rc_ = h->aV.ensure(8 * sB * m))) return rc_;
+  if ((rc_ = upload(h->aU0, U_initial, sizeof(double) * sB * n * k, s))) return rc_;
+  if ((rc_ = h->aU.ensure(8 * sB * n * k))) return rc_;
+  if ((rc_ = h->aV.ensure(8 * sB * m * k))) return rc_;
   if ((rc_ = h->aobj.ensure(8 * sB * max_iters))) return rc_;
   if ((rc_ = h->aint.ensure(4 * sB * 2))) return rc_;
   if ((rc_ = h->aG.ensure(8 * sB * Rmax * Rmax))) return rc_;
   AltminWS w{};
-  w.B = B; w.n = n; w.m = m; w.Rmax = Rmax; w.Lmax = Lmax; w.max_iters = max_iters;
+  w.B = B; w.n = n; w.m = m; w.k = k; w.Rmax = Rmax; w.Lmax = Lmax; w.max_iters = max_iters;
   w.gamma = h->gamma; w.eps = eps; w.sumA2 = h->sumA2;
   w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
   w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>(); w.row_val = h->drow_val.as<double>();
-  w.R = h->aR.as<int>(); w.rkind = h->arkind.as<int>(); w.rcut = h->arcut.as<int>(); w.rbi = h->arbi.as<int>();
+  w.R = h->aR.as<int>(); w.rkind = h->arkind.as<int>(); w.rcut = h->arcut.as<int>(); w.rbi = h->arbi.as<int>(); w.rbj = h->arbj.as<int>();
   w.rcoef = h->arcoef.as<double>(); w.rrhs = h->arrhs.as<double>(); w.cutx = h->acutx.as<double>();
   w.U0 = h->aU0.as<double>(); w.U = h->aU.as<double>(); w.V = h->aV.as<double>(); w.objectives = h->aobj.as<double>();
   w.converged = h->aint.as<int>(); w.n_iters = h->aint.as<int>() + B; w.G = h->aG.as<double>();
-  const size_t lds = ((size_t)4 * n + m + 2 * Rmax + 8) * 8;
-  if (lds + 8 * 1024 > OMC_MAX_DYN_LDS) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: n, m too large for the LDS-resident kernel of this round");
-  omc_launch_altmin(&w, lds, s);
-  HIPCHK(hipMemcpyAsync(U, w.U, 8 * sB * n, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(V, w.V, 8 * sB * m, hipMemcpyDeviceToHost, s));
+  const size_t lds = (k == 1) ? ((size_t)4 * n + m + 2 * Rmax + 8) * 8
+                              : ((size_t)4 * n * k + (size_t)2 * n * k * k + (size_t)k * m + 2 * Rmax + 8) * 8;
+  if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS : (size_t)128 * 1024)) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: n, m too large for the LDS-resident kernel of this round");
+  if (k == 1) omc_launch_altmin(&w, lds, s); else omc_launch_altmin_k(&w, lds, s);
+  HIPCHK(hipMemcpyAsync(U, w.U, 8 * sB * n * k, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(V, w.V, 8 * sB * m * k, hipMemcpyDeviceToHost, s));
   if (objectives) HIPCHK(hipMemcpyAsync(objectives, w.objectives, 8 * sB * max_iters, hipMemcpyDeviceToHost, s));
   if (converged) HIPCHK(hipMemcpyAsync(converged, w.converged, 4 * sB, hipMemcpyDeviceToHost, s));
   if (n_iters) HIPCHK(hipMemcpyAsync(n_iters, w.n_iters, 4 * sB, hipMemcpyDeviceToHost, s));

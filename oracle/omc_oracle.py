@@ -832,11 +832,97 @@ def _ustep_quadratic(inst, V):
     return H, gv, const
 
 
-def altmin_u_step(inst, V, cuts=(), cut_type="linear", U_lower=None, U_upper=None, reference_quirk_q1=True):
+def quadratic_constraint_vectors(k):
+    """w_c, r_c of the quadratic constraints sum_i (w_c' u_i)^2 <= r_c of model_U: the k unit balls (OMC.jl:2164-2171), then
+    for every pair j1 < j2 the two cones ||U_j1 + U_j2||^2 <= 2, ||U_j1 - U_j2||^2 <= 2 (OMC.jl:2029-2045)."""
+    W = []; rad = []
+    for j in range(k):
+        e = np.zeros(k); e[j] = 1.0; W.append(e); rad.append(1.0)
+    for j1 in range(k - 1):
+        for j2 in range(j1 + 1, k):
+            for sg in (1.0, -1.0):
+                e = np.zeros(k); e[j1] = 1.0; e[j2] = sg; W.append(e); rad.append(2.0)
+    return np.array(W), np.array(rad)
+
+
+def _ustep_dual_newton(H, gv, Cm, d, const, tol=1e-12, max_newton=60):
+    """Exact dual method for model_U with k > 1 (mirrored by k_altmin on the GPU).
+    Multipliers theta_c >= 0 of the k^2 quadratic constraints shift every row Hessian by the same k x k matrix
+    S(theta) = 2 sum_c theta_c w_c w_c'; for fixed theta the problem is the row-separable QP with linear rows of the k = 1 case
+    (active-set NNQP on the Gram matrix C H(theta)^-1 C').  Outer: semismooth Newton on the complementarity system
+    min(theta, -q(theta)) = 0, q_c = sum_i (w_c' u_i)^2 - r_c, Jacobian by forward differences (symmetrised, ridge 1e-12),
+    projected step with backtracking on the residual norm."""
+    n, k = gv.shape
+    R = Cm.shape[0]
+    W, rad = quadratic_constraint_vectors(k)
+    mq = len(rad)
+
+    def evaluate(theta):
+        S = 2.0 * np.einsum("c,ca,cb->ab", theta, W, W)
+        Hinv = np.linalg.inv(H + S[None])
+        U0 = np.einsum("iab,ib->ia", Hinv, gv)
+        mu = np.zeros(R)
+        U = U0
+        if R:
+            T = np.einsum("ria,iab->rib", Cm, Hinv)
+            G = np.einsum("rib,sib->rs", T, Cm)
+            cc = np.einsum("ria,ia->r", Cm, U0) - d
+            mu = nnqp(G, cc)
+            U = U0 - np.einsum("r,rib->ib", mu, T)
+        q = ((U @ W.T) ** 2).sum(0) - rad
+        return U, q, mu
+
+    def dual_value(theta, U, q):
+        return 0.5 * float(np.einsum("ia,iab,ib->", U, H, U)) - float((gv * U).sum()) + float(theta @ q)
+
+    theta = np.zeros(mq)
+    U, q, mu = evaluate(theta)
+    dv = dual_value(theta, U, q)
+    res = float(np.abs(np.minimum(theta, -q)).max())
+    it = 0
+    lm = 1e-10                                   # Levenberg-Marquardt weight relative to the mean diagonal of -J
+    while res > tol and it < max_newton:
+        it += 1
+        act = [c for c in range(mq) if theta[c] > 0.0 or q[c] > 0.0]
+        J = np.zeros((len(act), len(act)))
+        for a, c in enumerate(act):
+            dl = 1e-7 * max(1.0, theta[c])
+            th2 = theta.copy(); th2[c] += dl
+            _, q2, _ = evaluate(th2)
+            J[:, a] = (q2[act] - q[act]) / dl
+        P = -0.5 * (J + J.T)
+        scale = max(float(np.trace(P)), 1e-300) / len(act)
+        accepted = False
+        for _try in range(40):                   # maximise the concave dual: damped projected Newton step, ascent test on d
+            try:
+                Lc = np.linalg.cholesky(P + (lm * scale) * np.eye(len(act)))
+                step = np.linalg.solve(Lc.T, np.linalg.solve(Lc, q[act]))
+            except np.linalg.LinAlgError:
+                lm *= 10.0
+                continue
+            th_new = theta.copy()
+            th_new[act] = np.maximum(theta[act] + step, 0.0)
+            Un, qn, mun = evaluate(th_new)
+            dn = dual_value(th_new, Un, qn)
+            rn = float(np.abs(np.minimum(th_new, -qn)).max())
+            if dn >= dv + 1e-4 * float(q @ (th_new - theta)) - 1e-14 * max(1.0, abs(dv)) and (dn > dv or rn < res):
+                theta, U, q, mu, res, dv = th_new, Un, qn, mun, rn, dn
+                lm = max(lm * 0.1, 1e-12)
+                accepted = True
+                break
+            lm *= 10.0
+        if not accepted:
+            break
+    obj = 0.5 * float(np.einsum("ia,iab,ib->", U, H, U)) - float((gv * U).sum()) + const
+    return U, obj, dict(theta=theta, lam=mu, newton_iters=it, kkt_residual=res)
+
+
+def altmin_u_step(inst, V, cuts=(), cut_type="linear", U_lower=None, U_upper=None, reference_quirk_q1=True, method="dual"):
     """model_U (OMC.jl:2014-2093, 2164-2171, 2213-2228): convex QP with box, ||U_j||<=1,
     ||U_j1 +- U_j2|| <= sqrt 2 and the per-cut bounds on v = U'x (NOT the aggregated cut row).
     k = 1: exact dual method (multiplier of the ball by bracketing + active-set NNQP for the rows).
-    k > 1: scipy SLSQP on the same QP (independent implementation; small sizes only)."""
+    k > 1: method="dual" (default): exact dual Newton method, mirrored by the GPU; method="slsqp": scipy SLSQP on the
+    same QP (independent implementation used to validate the former; small sizes only)."""
     n, k = inst.n, inst.k
     H, gv, const = _ustep_quadratic(inst, V)
     rows = build_rows(inst, cuts, cut_type, U_lower, U_upper, reference_quirk_q1)
@@ -880,6 +966,8 @@ def altmin_u_step(inst, V, cuts=(), cut_type="linear", U_lower=None, U_upper=Non
         obj = 0.5 * float((h * u * u).sum()) - float(gg @ u) + const
         return Un, obj, dict(theta=theta, lam=lam, rows=[rows.kinds[r] for r in sel])
     # ---- k > 1 -----------------------------------------------------------------------------------------
+    if method == "dual":
+        return _ustep_dual_newton(H, gv, C.reshape(len(sel), n, k), d, const)
     from scipy.optimize import minimize
 
     def q(u):

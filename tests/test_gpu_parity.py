@@ -367,6 +367,19 @@ def test_anderson_acceleration_option(have_gpu, omc, orc):
     eng.close()
 
 
+def test_branch_and_bound_rank2_smoke(have_gpu, omc, orc):
+    """Rank-2 tree (4 children per node, GPU altmin for k = 2): counters and bounds stay consistent."""
+    A, mask = orc.make_instance(16, 20, 2, seed=13, kind="lowrank", n_indices=int(0.4 * 16 * 20))
+    eng = omc.Engine(A, mask, GAMMA, 2)
+    sol, inst = omc.pkg.bnb.branch_and_bound(eng, A, mask, gap=1e-4, time_limit=60.0, batch=16, rho_scale=4.0, use_max_steps=True, max_steps=60)
+    c = inst["run_details"]; log = np.array(inst["run_log"])
+    assert c["nodes_dominated"] + c["nodes_relax_infeasible"] + c["nodes_relax_feasible"] == c["nodes_explored"]
+    assert (np.diff(log[:, 3]) >= -1e-9).all() and sol["lower_bound"] <= sol["objective"] * (1 + 1e-9)
+    assert np.linalg.matrix_rank(sol["X"], tol=1e-8) <= 2
+    assert sol["objective"] == pytest.approx(orc.evaluate_objective(sol["X"], A, mask, GAMMA), rel=1e-10)
+    eng.close()
+
+
 def test_branch_and_bound_invariants(have_gpu, omc, orc):
     """Driver counterpart (bnb.branch_and_bound) on the README-type 20 x 24 instance: the per-run invariants of SURVEY 8c --
     LB monotone, LB <= UB, counter identity (OMC.jl:411-425), incumbent = evaluate_objective(X) of a rank-k X, and a root
@@ -387,4 +400,33 @@ def test_branch_and_bound_invariants(have_gpu, omc, orc):
     root = orc.sdp_relaxation(inst_o, params=orc.RelaxParams(rho_scale=16.0), want_certificate=False)
     assert log[0, 3] == pytest.approx(root["dual_bound"], rel=2e-6)                   # first logged LB = certified root bound
     assert root["dual_bound"] <= sol["objective"] * (1 + 1e-9)
+    eng.close()
+
+
+@pytest.mark.parametrize("k,cut_type", [(2, "linear"), (2, "linear3"), (3, "linear2")])
+def test_altmin_rank_k_matches_oracle(have_gpu, omc, orc, k, cut_type):
+    """alternating_minimization for k > 1 (k_altmin_k): k^2 quadratic constraints by projected Newton on the dual, mirrored by the
+    oracle's _ustep_dual_newton (itself validated against SLSQP in the CPU suite)."""
+    n, m = 16, 22
+    A, mask = orc.make_instance(n, m, k, seed=70 + k, kind="lowrank", n_indices=int(0.5 * n * m))
+    inst = orc.Instance(A, mask, GAMMA, k)
+    eng = omc.Engine(A, mask, GAMMA, k)
+    U0 = orc.svd_rounding(np.where(mask, A, 0.0), k)
+    rng = np.random.default_rng(2)
+    dirs = orc.child_directions(cut_type, k)
+    x1 = np.linalg.qr(rng.standard_normal((n, 1)))[0][:, 0]; x2 = np.linalg.qr(rng.standard_normal((n, 1)))[0][:, 0]
+    node_sets = [[], [(x1, U0 * 0.6, list(dirs[1]))], [(x1, U0 * 0.6, list(dirs[-1])), (x2, -U0 * 0.3, list(dirs[0]))]]
+    starts = [U0, U0, U0 + 0.05 * rng.standard_normal((n, k))]
+    got = eng.alternating_minimization(starts, node_sets, cut_type, max_iters=40)
+    W, rad = orc.quadratic_constraint_vectors(k)
+    for g, cuts, u0 in zip(got, node_sets, starts):
+        r = orc.alternating_minimization(inst, u0, cuts, cut_type, max_iters=40)
+        assert g["converged"] == r["converged"] and g["n_iters"] == r["n_iters"]
+        assert np.allclose(g["objectives"], r["objectives"], rtol=1e-8)
+        assert np.allclose(g["U"] @ g["V"], r["U"] @ r["V"], atol=1e-5)
+        assert (((g["U"] @ W.T) ** 2).sum(0) - rad).max() <= 1e-9                       # balls and pair cones (OMC.jl:2029-2045, 2164-2171)
+        for j in range(k):
+            assert (g["U"][n - k + j:, j] >= -1e-10).all()                               # symmetry breaking (OMC.jl:1989-1996)
+        X = g["U"] @ g["V"]
+        assert g["objectives"][-1] == pytest.approx(orc.evaluate_objective(X, A, mask, GAMMA), rel=1e-9)   # model_U objective = master objective at (U, V)
     eng.close()

@@ -260,3 +260,25 @@ def test_oracle_anderson_acceleration_converges_crawling_node(orc):
     assert r["termination_status"] == 0 and r["iters"] <= 500 and r["n_aa"] > 10
     assert r["objective"] == pytest.approx(float(z["objective"][2]), rel=2e-6)
     assert r["objective"] - r["dual_bound"] <= 1e-6 * max(1.0, abs(r["objective"]))
+
+
+def test_ustep_dual_newton_matches_slsqp(orc):
+    """Rank k > 1 U-step of altmin: the exact dual Newton method (what the GPU mirrors) against scipy SLSQP on the same QP."""
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        k = 2 if trial % 3 else 3
+        n = int(rng.integers(8, 14)); m = n + int(rng.integers(0, 6))
+        A, mask = orc.make_instance(n, m, k, seed=100 + trial, kind="lowrank", n_indices=max(int(0.6 * n * m), (n + m) * k))
+        sc = float(10 ** rng.uniform(-1, 1))
+        inst = orc.Instance(A * sc, mask, 80.0, k)
+        V = rng.standard_normal((k, m)) * sc
+        cuts = []
+        for _ in range(int(rng.integers(0, 3))):
+            x = rng.standard_normal(n); x /= np.linalg.norm(x)
+            cuts.append((x, rng.standard_normal((n, k)) * 0.3, [["left", "right"][int(rng.integers(2))] for _ in range(k)]))
+        U1, o1, i1 = orc.altmin_u_step(inst, V, cuts, "linear", method="dual")
+        U2, o2, i2 = orc.altmin_u_step(inst, V, cuts, "linear", method="slsqp")
+        W, rad = orc.quadratic_constraint_vectors(k)
+        assert i1["kkt_residual"] <= 1e-9 and (((U1 @ W.T) ** 2).sum(0) - rad).max() <= 1e-9
+        if i2["slsqp_status"] == 0:
+            assert o1 == pytest.approx(o2, rel=1e-7) and o1 <= o2 + 1e-9 * max(1.0, abs(o2))
