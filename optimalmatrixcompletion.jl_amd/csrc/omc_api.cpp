@@ -67,7 +67,7 @@ struct omc_instance {
   // batch workspace
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
-  DevBuf baaF, baaG, baaZ, baaS, baaI;
+  DevBuf baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
   DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow;
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
   OmcWS ws{};
@@ -196,7 +196,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
-                   &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
+                   &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -418,6 +418,12 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   HIPCHK(hipMemsetAsync(h->blamD.p, 0, sB * m * n * 8, h->stream));
   w.lamD = h->blamD.as<double>();
   w.Mbuf = h->bMbuf.as<double>(); w.Vrow = h->bVrow.as<double>();
+  if (!getenv("OMC_COLD_CHECK")) {   // warm-started eigenvalues for the certificate matrix
+    ENS(h->bMbufC, sB * w.np16 * w.np16 * 8); ENS(h->bVrowC, sB * w.np16 * w.np16 * 8); ENS(h->bchkS, sB * 8); ENS(h->bchkI, sB * sizeof(int));
+    HIPCHK(hipMemsetAsync(h->bMbufC.p, 0, sB * w.np16 * w.np16 * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->bchkI.p, 0, sB * sizeof(int), h->stream));
+    w.MbufC = h->bMbufC.as<double>(); w.VrowC = h->bVrowC.as<double>(); w.fro2c = h->bchkS.as<double>(); w.vvalidC = h->bchkI.as<int>();
+  }
   w.Y = h->bY.as<double>(); w.Yp = h->bYp.as<double>(); w.U = h->bU.as<double>();
   w.D1 = h->bD1.as<double>(); w.D3 = h->bD3.as<double>(); w.W1 = h->bW1.as<double>(); w.E3 = h->bE3.as<double>();
   w.dS = h->bdS.as<double>();
@@ -652,7 +658,8 @@ int omc_relax_solve(omc_instance* h) {
       omc_launch_check_zero(&w, s);
       omc_launch_colprox(&w, 1, s);
       omc_launch_check_build(&w, s);
-      omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
+      if (h->ws_lpp && w.MbufC) { OmcWS wc = w; wc.ws_mode = 1; omc_launch_cone_ws(&wc, h->ws_lpp, h->ws_use_lds, h->ws_lds, s); }
+      else omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
       omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, s);      // per-slot iteration cap is applied on the device
       if (w.bump_max > 0) omc_launch_rho_rescale(&w, s);
       if (w.accel) omc_launch_aa(&w, s);      // after the certificate (computed on an image of the map), skips finished slots

@@ -64,6 +64,8 @@ struct OmcWS {
   double *Mbuf, *Vrow;    // np16*np16: next cone input Y - D1 (zero padded) ; eigenvectors of the last projection, row-major
   double* fro2;           // B: ||Mbuf||_F^2
   int* vvalid;            // B: Vrow holds eigenvectors
+  // the same triple for the certificate matrix Mchk (k_cone_ws with ws_mode = 1 returns the k smallest eigenvalues only)
+  double *MbufC, *VrowC, *fro2c; int* vvalidC; int ws_mode;
   // rows
   int* R;                 // B
   int *rkind, *rcut, *rbi, *rbj;  // B*Rmax

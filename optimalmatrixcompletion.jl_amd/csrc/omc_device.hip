@@ -79,7 +79,7 @@ __global__ void k_setup(OmcWS w) {
       w.Mbuf[(size_t)b * NP * NP + e] = (i == j && i < n) ? d0 : 0.0;
       w.Vrow[(size_t)b * NP * NP + e] = 0.0;
     }
-    if (tid == 0) { w.fro2[b] = d0 * d0 * n; w.vvalid[b] = 0; }
+    if (tid == 0) { w.fro2[b] = d0 * d0 * n; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0; }
   }
   for (int e = tid; e < n * k; e += T) w.U[(size_t)b * n * k + e] = 0.0;
   for (int e = tid; e < rm * k; e += T) {
@@ -777,9 +777,11 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   auto ev = Gm + (size_t)Np * ld;
   auto wgt = ev + Np;
   int* sel = (int*)(wgt + Np);
-  const double* Mb = w.Mbuf + (size_t)b * NP * NP;
-  double* Vr = w.Vrow + (size_t)b * NP * NP;
-  const double sigma = 1.5 * sqrt(w.fro2[b]) + 1e-300;
+  const int evals_only = w.ws_mode;   // 1: certificate matrix (k_check_build), return sum of min(lambda_i, 0) over the k smallest
+  const double* Mb = (evals_only ? w.MbufC : w.Mbuf) + (size_t)b * NP * NP;
+  double* Vr = (evals_only ? w.VrowC : w.Vrow) + (size_t)b * NP * NP;
+  int* vvalid = evals_only ? w.vvalidC : w.vvalid;
+  const double sigma = 1.5 * sqrt(evals_only ? w.fro2c[b] : w.fro2[b]) + 1e-300;
   const int wv = tid >> 6, lane = tid & 63, nw = T >> 6;
   STAMP_BEGIN();
   DIAG_T0();
@@ -788,7 +790,7 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
   for (int e = tid; e < Np * ld; e += T) Gm[e] = 0.0;
   __syncthreads();
   STAMP(6);
-  if (!w.vvalid[b]) {
+  if (!vvalid[b]) {
     for (int e = tid; e < N * N; e += T) {
       int i = e % N, j = e / N;
       Gm[(size_t)j * ld + i] = Mb[(size_t)j * NP + i] + ((i == j) ? sigma : 0.0);
@@ -909,8 +911,23 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
     int t = e % N, kk = e / N;     // consecutive threads -> consecutive t -> contiguous row-major store
     Vr[(size_t)kk * NP + t] = Gm[(size_t)t * ld + kk] * rsqrt(ev[t]);
   }
-  if (tid == 0) w.vvalid[b] = 1;
+  if (tid == 0) vvalid[b] = 1;
   STAMP(2);
+  if (evals_only) {
+    if (tid == 0) {
+      const int k = w.k;
+      double best[8]; const int kk2 = (k < 8) ? k : 8;
+      for (int i = 0; i < kk2; ++i) best[i] = 1e300;
+      for (int t = 0; t < N; ++t) {
+        double lamv = sqrt(ev[t]) - sigma;
+        for (int i = 0; i < kk2; ++i) if (lamv < best[i]) { const double tmp = best[i]; best[i] = lamv; lamv = tmp; }
+      }
+      double s2 = 0.0;
+      for (int i = 0; i < kk2; ++i) s2 += fmin(best[i], 0.0);
+      w.evsum[b] = s2;
+    }
+    return;
+  }
   // ---- 4. clip: rebuild either the defect or the kept part --------------------------------------------------------
   // eigenvalues in parallel (the square roots), then one lane compacts the selected columns (integer work only)
   double* lamv_s = (double*)(sel + Np + (Np & 1));
@@ -1379,6 +1396,17 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
       if (w.rkind[(size_t)nb * w.Rmax + rr] != ROW_TRACE) cst -= lam[rr] * w.rrhs[(size_t)nb * w.Rmax + rr];
     for (int j = 0; j < k; ++j) cst -= rho * w.Q3T[(size_t)b * k * k + (size_t)j * k + j];
     w.cpen[b] = pen; w.cst[b] = cst;
+  }
+  if (w.MbufC) {   // zero-padded copy + Frobenius norm for the warm-started eigenvalue kernel
+    const int NP = w.np16;
+    double fr2 = 0.0;
+    for (int e = tid; e < n * n; e += T) {
+      const int i = e % n, j = e / n;
+      const double mv = 0.5 * (M[e] + M[(size_t)i * n + j]);
+      w.MbufC[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
+    }
+    fr2 = block_sum(fr2, red);
+    if (tid == 0) w.fro2c[b] = fr2;
   }
 }
 
