@@ -544,7 +544,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     }
     {
       const int N3 = rmax + k; const int Npm = (N3 + 1) & ~1, ldm = Npm | 1;
-      h->small_lds = ((size_t)n * rmax + (size_t)N3 * N3 + (size_t)Npm * ldm + 2 * Npm + (size_t)rmax * k + 8) * 8 + (size_t)(Npm + 2) * 4 + 16;
+      h->small_lds = ((size_t)n * rmax + (size_t)N3 * N3 + (size_t)Npm * ldm + 2 * Npm + (size_t)rmax * k + 8 + (size_t)n * 16 + 4) * 8 + (size_t)(Npm + 2) * 4 + 16;   // + Q' staging (n x 16)
       h->small_use_lds = h->small_lds + 1024 <= OMC_MAX_DYN_LDS;
       if (!h->small_use_lds) {
         w.small_scratch_stride = h->small_lds / 8 + 8;

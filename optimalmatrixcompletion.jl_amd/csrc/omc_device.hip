@@ -497,6 +497,50 @@ __device__ __forceinline__ int jacobi_sweeps_t(double* Gm, double* nrm2, int Nr,
   return sweeps;
 }
 
+// The same sweep for tiny matrices (Np <= 16), entirely inside wave 0: 8 pair groups of 8 lanes, each lane owns rows lg and lg + 8,
+// wave barriers instead of workgroup barriers (a 12 x 12 small-cone matrix took 117 us with __syncthreads per step, ~10 us so).
+__device__ __forceinline__ int jacobi_sweeps_wave16(double* Gm, double* nrm2, int Nr, int Np, int ld, double tau, int max_sweeps) {
+  const int lane = threadIdx.x & 63, grp = lane >> 3, lg = lane & 7;
+  const int npairs = Np >> 1;
+  const double tau2 = tau * tau;
+  int sweeps = 0;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    if (lane < Np) {
+      double a = 0.0;
+      if (lane < Nr) for (int r = 0; r < Nr; ++r) { const double x = Gm[(size_t)lane * ld + r]; a += x * x; }
+      nrm2[lane] = a;
+    }
+    WAVE_SYNC();
+    int rotated = 0;
+    for (int step = 0; step < Np - 1; ++step) {
+      if (grp < npairs) {
+        int p, q;
+        rr_pair(step, grp, Np, p, q);
+        double* gp = Gm + (size_t)p * ld;
+        double* gq = Gm + (size_t)q * ld;
+        const bool r0 = lg < Nr, r1 = lg + 8 < Nr;
+        const double x0 = r0 ? gp[lg] : 0.0, x1 = r1 ? gp[lg + 8] : 0.0, y0 = r0 ? gq[lg] : 0.0, y1 = r1 ? gq[lg + 8] : 0.0;
+        const double gm = group_sum_dpp<8>(x0 * y0 + x1 * y1);
+        const double a = nrm2[p], bb = nrm2[q];
+        if (gm * gm > tau2 * a * bb && a > 0.0 && bb > 0.0) {
+          const double zeta = (bb - a) / (2.0 * gm);
+          const double az = fabs(zeta);
+          double tt = 1.0 / (az + sqrt(1.0 + az * az));
+          tt = (zeta >= 0.0) ? tt : -tt;
+          const double cs = rsqrt(1.0 + tt * tt), sn = cs * tt;
+          if (r0) { gp[lg] = cs * x0 - sn * y0; gq[lg] = sn * x0 + cs * y0; }
+          if (r1) { gp[lg + 8] = cs * x1 - sn * y1; gq[lg + 8] = sn * x1 + cs * y1; }
+          if (lg == 0) { nrm2[p] = a - tt * gm; nrm2[q] = bb + tt * gm; }
+          rotated = 1;
+        }
+      }
+      WAVE_SYNC();
+    }
+    if (!__any(rotated)) { ++sweeps; break; }
+  }
+  return sweeps;
+}
+
 // generic fall-back (any N, rows not cached): used when a lane would own more than JROWS rows
 __device__ __forceinline__ int jacobi_onesided(double* Gm, int Nr, int Np, int ld, int lpp, double tau, int max_sweeps, int* s_cnt) {
   const int tid = threadIdx.x, T = blockDim.x;
@@ -609,8 +653,11 @@ __device__ __forceinline__ double eig_frontend(double* Gm, double* ev, int N, in
   while (lpp > 1 && lpp * (Np >> 1) > T) lpp >>= 1;
   if (lpp > 16) lpp = 16;
   const double tau = tau_in;
-  int sweeps;
-  if (lpp >= 4 && (N + lpp - 1) / lpp <= JROWS) {
+  int sweeps = 0;
+  if (Np <= 16) {
+    if (tid < WAVE) sweeps = jacobi_sweeps_wave16(Gm, ev, N, Np, ld, tau, 30);
+    __syncthreads();
+  } else if (lpp >= 4 && (N + lpp - 1) / lpp <= JROWS) {
     // ev doubles as the norm cache during the sweeps (recomputed below)
     if (lpp == 16) sweeps = jacobi_sweeps_t<16>(Gm, ev, N, Np, ld, tau, 30);
     else if (lpp == 8) sweeps = jacobi_sweeps_t<8>(Gm, ev, N, Np, ld, tau, 30);
@@ -1000,6 +1047,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   double* wgt = ev + Npm;
   int* sel = (int*)(wgt + Npm);
   double* Cc = (double*)(sel + Npm + (Npm & 1));  // r x k coefficients (recover)
+  double* Qs = Cc + (size_t)rm * k + 2;          // n x 16: Q' padded with zero columns (LDS variant only, r <= 16)
   const double* Q = w.Qb + (size_t)nb * n * rm;
   const double* Y = w.Y + (size_t)b * n * n;
   const double* D3 = w.D3 + (size_t)b * n * n;
@@ -1007,14 +1055,50 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   STAMP_BEGIN();
   DIAG_T0();
   // T1 = (Y - D3) Q   or  Y Q
-  for (int e = tid; e < n * r; e += T) {
-    int i = e % n, a = e / n;
-    double acc = 0.0;
-    if (mode == SMALL_PROJ) for (int j = 0; j < n; ++j) acc += (Y[(size_t)j * n + i] - D3[(size_t)j * n + i]) * Q[(size_t)a * n + j];
-    else for (int j = 0; j < n; ++j) acc += Y[(size_t)j * n + i] * Q[(size_t)a * n + j];
-    T1[(size_t)a * n + i] = acc;
+  constexpr int T1_RS = 16;
+  if (USE_LDS && r <= T1_RS && n <= T) {
+    // Q' staged in LDS, padded to 16 columns: the inner loop has no conditional loads (a guarded load keeps hipcc from
+    // overlapping the memory latencies).  One thread per (row i, slice of the j range): every Y / D3 entry is loaded once.
+    for (int e = tid; e < n * T1_RS; e += T) { const int j = e / T1_RS, a = e % T1_RS; Qs[e] = (a < r) ? Q[(size_t)a * n + j] : 0.0; }
+    __syncthreads();
+    int H = T / n; if (H > 8) H = 8;
+    const int i = tid % n, hh = tid / n;
+    double acc[T1_RS];
+#pragma unroll
+    for (int a = 0; a < T1_RS; ++a) acc[a] = 0.0;
+    if (hh < H) {
+      const int j0 = (int)((long)n * hh / H), j1 = (int)((long)n * (hh + 1) / H);
+      if (mode == SMALL_PROJ) {
+        for (int j = j0; j < j1; ++j) {
+          const double yv = Y[(size_t)j * n + i] - D3[(size_t)j * n + i];
+#pragma unroll
+          for (int a = 0; a < T1_RS; ++a) acc[a] += yv * Qs[j * T1_RS + a];
+        }
+      } else {
+        for (int j = j0; j < j1; ++j) {
+          const double yv = Y[(size_t)j * n + i];
+#pragma unroll
+          for (int a = 0; a < T1_RS; ++a) acc[a] += yv * Qs[j * T1_RS + a];
+        }
+      }
+    }
+    for (int h2 = 0; h2 < H; ++h2) {      // slices are added in a fixed order (deterministic sums)
+      if (hh == h2) {
+#pragma unroll
+        for (int a = 0; a < T1_RS; ++a) if (a < r) T1[(size_t)a * n + i] = (h2 == 0 ? 0.0 : T1[(size_t)a * n + i]) + acc[a];
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int e = tid; e < n * r; e += T) {
+      int i = e % n, a = e / n;
+      double acc = 0.0;
+      if (mode == SMALL_PROJ) for (int j = 0; j < n; ++j) acc += (Y[(size_t)j * n + i] - D3[(size_t)j * n + i]) * Q[(size_t)a * n + j];
+      else for (int j = 0; j < n; ++j) acc += Y[(size_t)j * n + i] * Q[(size_t)a * n + j];
+      T1[(size_t)a * n + i] = acc;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   STAMP(16);
   // M3
   for (int e = tid; e < N3 * N3; e += T) {
@@ -1109,12 +1193,22 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   }
   __syncthreads();
   double* E3 = w.E3 + (size_t)b * n * n;
-  for (int e = tid; e < n * n; e += T) {
-    int i = e % n, j = e / n;
-    if (i < j) continue;
-    double acc = 0.0;
-    for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Q[(size_t)a * n + j];
-    E3[(size_t)j * n + i] = acc; E3[(size_t)i * n + j] = acc;
+  if (USE_LDS && r <= 16 && n <= T) {
+    // every entry on its own (coalesced stores, no transposed write): both operands come from LDS (T1 and the staged Q')
+    for (int e = tid; e < n * n; e += T) {
+      const int i = e % n, j = e / n;
+      double acc = 0.0;
+      for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Qs[j * 16 + a];
+      E3[e] = acc;
+    }
+  } else {
+    for (int e = tid; e < n * n; e += T) {
+      int i = e % n, j = e / n;
+      if (i < j) continue;
+      double acc = 0.0;
+      for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Q[(size_t)a * n + j];
+      E3[(size_t)j * n + i] = acc; E3[(size_t)i * n + j] = acc;
+    }
   }
   STAMP(20);
   if (tid == 0) DIAG_CYC(5, b);
@@ -1228,23 +1322,33 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   STAMP(9);
   // 3. c = A t - b
   const double* cutx = w.cutx + (size_t)nb * w.Lmax * n;
-  for (int rr = 0; rr < R; ++rr) {
-    const int kind = w.rkind[(size_t)nb * w.Rmax + rr];
-    double acc = 0.0;
-    if (kind == ROW_TRACE) {
-      for (int i = tid; i < n; i += T) acc += tY[(size_t)i * n + i];
-    } else if (kind == ROW_BOX) {
-      if (tid == 0) acc = w.rcoef[((size_t)nb * w.Rmax + rr) * k] * tU[(size_t)w.rbj[(size_t)nb * w.Rmax + rr] * n + w.rbi[(size_t)nb * w.Rmax + rr]];
-    } else {
-      const double* x = cutx + (size_t)w.rcut[(size_t)nb * w.Rmax + rr] * n;
-      const double* cf = w.rcoef + ((size_t)nb * w.Rmax + rr) * k;
-      if (kind == ROW_CUT) {
-        for (int e = tid; e < n * n; e += T) { int i = e % n, j = e / n; acc += x[i] * x[j] * tY[e]; }
+  {   // one WAVE per row (wave-level reductions, no workgroup barrier per row); a cut row is x'(tY x) with lane = row index
+    const int wv_ = tid >> 6, lane_ = tid & 63, nw_ = T >> 6;
+    for (int rr = wv_; rr < R; rr += nw_) {
+      const int kind = w.rkind[(size_t)nb * w.Rmax + rr];
+      double acc = 0.0;
+      if (kind == ROW_TRACE) {
+        for (int i = lane_; i < n; i += WAVE) acc += tY[(size_t)i * n + i];
+      } else if (kind == ROW_BOX) {
+        if (lane_ == 0) acc = w.rcoef[((size_t)nb * w.Rmax + rr) * k] * tU[(size_t)w.rbj[(size_t)nb * w.Rmax + rr] * n + w.rbi[(size_t)nb * w.Rmax + rr]];
+      } else {
+        const double* x = cutx + (size_t)w.rcut[(size_t)nb * w.Rmax + rr] * n;
+        const double* cf = w.rcoef + ((size_t)nb * w.Rmax + rr) * k;
+        if (kind == ROW_CUT) {
+          for (int i = lane_; i < n; i += WAVE) {
+            double s2 = 0.0;
+            for (int j = 0; j < n; ++j) s2 += x[j] * tY[(size_t)j * n + i];
+            acc += x[i] * s2;
+          }
+        }
+        for (int j = 0; j < k; ++j) {
+          const double cj = cf[j];
+          if (cj != 0.0) for (int i = lane_; i < n; i += WAVE) acc += cj * x[i] * tU[(size_t)j * n + i];
+        }
       }
-      for (int e = tid; e < n * k; e += T) { int i = e % n, j = e / n; if (cf[j] != 0.0) acc += cf[j] * x[i] * tU[e]; }
+      const double tot = wave_sum(acc);
+      if (lane_ == 0) cvec[rr] = tot - w.rrhs[(size_t)nb * w.Rmax + rr];
     }
-    double tot = block_sum(acc, red);
-    if (tid == 0) cvec[rr] = tot - w.rrhs[(size_t)nb * w.Rmax + rr];
   }
   __syncthreads();
   STAMP(10);
