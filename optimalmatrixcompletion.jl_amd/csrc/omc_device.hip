@@ -936,6 +936,9 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
               }
             }
             if (lg == 0) { ev[p] = a - tt * gm; ev[q] = bb + tt * gm; }
+#ifdef OMC_STAMPS
+            if (lg == 0 && b == 0 && !evals_only) atomicAdd(&w.stamps[32 + (size_t)6 * w.B + (sweeps < 8 ? sweeps : 7)], 1.0);   // rotations per sweep index (slot 0)
+#endif
             if (g2 > tau * ab) big = 1;   // relative cross product above sqrt(tau): one more sweep needed
           }
         }
@@ -944,6 +947,9 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
       if (!__syncthreads_or(big)) { ++sweeps; break; }   // all cross products were < 1e-7 relative: now < 1e-14
     }
     if (tid == 0) w.sweeps[b] += sweeps;
+#ifdef OMC_STAMPS
+    if (tid == 0 && b == 0 && !evals_only) atomicAdd(&w.stamps[32 + (size_t)7 * w.B + (sweeps < 8 ? sweeps : 7)], 1.0);   // histogram of sweeps per call (slot 0)
+#endif
   }
   STAMP(1);
   // ---- 3. squared norms, eigenvectors for the next call ---------------------------------------------------------
