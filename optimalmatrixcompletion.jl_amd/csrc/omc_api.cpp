@@ -261,7 +261,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   const omc_relax_params& P = h->params;
   if (P.breakpoints != OMC_SMALLEST_1_EIGVEC && P.breakpoints != OMC_SMALLEST_2_EIGVEC)
     return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts breakpoints (OMC.jl:2440-2446)");
-  const int n = h->n, m = h->m, k = h->k, N = n + k;
+  const int n = h->n, m = h->m, k = h->k;
   // ---- rows (host) -----------------------------------------------------------------------------------
   int Lmax = 0; long Ltot = 0;
   for (int b = 0; b < B; ++b) {

@@ -844,7 +844,6 @@ __global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
     }
   } else {
     const int nt = NP >> 4;
-    const int K4 = (N + 3) & ~3;
     const int li = lane & 15, lk = lane >> 4;
     // software pipeline of depth PF k-steps with NO conditionals inside the K loop (a guarded load makes hipcc drain
     // vmcnt before every MFMA): K runs over the whole zero-padded NP (a multiple of 16 = 4*PF), the prefetch index wraps
