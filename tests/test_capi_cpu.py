@@ -100,3 +100,16 @@ def test_instance_and_node_log_round_trip(omc, tmp_path):
     assert data.compute_MSE(A, A, mask, "all") == 0.0
     with pytest.raises(ValueError):
         data.compute_MSE(A, A, mask, "bogus")
+
+
+def test_shor_and_altmin_argument_checks_without_a_handle(omc):
+    """NULL handles / pointers are rejected before anything touches the device (no GPU needed)."""
+    lib = omc.load()
+    cnt = np.zeros(1, dtype=np.int64); cl = np.array([4], dtype=np.int32)
+    assert lib.omc_shor_count(None, 1, omc.pkg._lib.ptr(cl), omc.pkg._lib.ptr(cnt)) == -3
+    assert lib.omc_shor_indexes(None, 1, omc.pkg._lib.ptr(cl), 0, None, omc.pkg._lib.ptr(cnt)) == -3
+    no = np.zeros(1, dtype=np.int32)
+    assert lib.omc_violated_shor_minors(None, None, 1, omc.pkg._lib.ptr(cl), 0, None, 10, None, None, omc.pkg._lib.ptr(no)) == -3
+    assert lib.omc_shor_last_stats(None, None, None) == -3
+    assert lib.omc_altmin_batch(None, 1, 0, 1, None, None, None, None, None, 1e-5, 10, 1.0, None, None, None, None, None, None) == -3
+    assert b"NULL" in lib.omc_last_error() or b"handle" in lib.omc_last_error()

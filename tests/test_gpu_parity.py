@@ -430,3 +430,19 @@ def test_altmin_rank_k_matches_oracle(have_gpu, omc, orc, k, cut_type):
         X = g["U"] @ g["V"]
         assert g["objectives"][-1] == pytest.approx(orc.evaluate_objective(X, A, mask, GAMMA), rel=1e-9)   # model_U objective = master objective at (U, V)
     eng.close()
+
+
+def test_time_limit_and_iteration_cap_statuses(have_gpu, omc, orc):
+    """MOI.TIME_LIMIT / SLOW_PROGRESS branches of the driver (OMC.jl:783-784, 841): values stay available, bounds stay valid."""
+    A, mask = orc.make_instance(24, 28, 1, seed=12, kind="lowrank", n_indices=int(0.4 * 24 * 28))
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    full = eng.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=4.0))[0]
+    assert full["status_code"] == 0
+    capped = eng.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=4.0, max_iters=50))[0]
+    assert capped["termination_status"] == "SLOW_PROGRESS" and capped["feasible"] and capped["iters"] == 50
+    assert capped["dual_bound"] <= full["objective"] * (1 + 1e-9)                       # still a valid lower bound
+    timed = eng.matrix_completion_SDP_relaxation([[], []], "linear", params=omc.default_params(rho_scale=4.0, time_limit=1e-9))
+    for o in timed:
+        assert o["termination_status"] == "TIME_LIMIT" and o["feasible"]
+        assert o["dual_bound"] <= full["objective"] * (1 + 1e-9)
+    eng.close()
