@@ -97,7 +97,7 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                      altmin_flag=True, max_altmin_probability=1.0, min_altmin_probability=0.005,
                      altmin_probability_decay_rate=1.1, use_max_steps=False, max_steps=1000000, time_limit=3600.0,
                      batch=64, rho_scale=None, params=None, seed=0, use_certified_bound=True, verbose=False,
-                     rank=0, world_size=1):
+                     rank=0, world_size=1, altmin_root_n_iters=1):
     """Behavioural counterpart of the reference driver for use_disjunctive_cuts = true, no Shor, one altmin run at the
     root (altmin_root_n_iters = 1).  Differences, all deliberate: (1) up to `batch` nodes are popped per round in the
     reference's selection order and relaxed in ONE GPU batch (batch=1 reproduces the serial order); (2) the node bound
@@ -133,8 +133,14 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     U0 = Uf[:, :k]
     solution = {}
     if altmin_flag:
-        am = engine.alternating_minimization([U0], [[]], disjunctive_cuts_type)[0]
-        X0 = am["U"] @ am["V"]
+        # OMC.jl:534-579: run 1 starts from the SVD of the zero-filled A, the others from it + sc * randn; all runs in ONE GPU
+        # batch, the best objective wins
+        sc = float(np.abs(U0).max())
+        starts = [U0] + [U0 + sc * rng.standard_normal((n, k)) for _ in range(max(int(altmin_root_n_iters), 1) - 1)]
+        ams = engine.alternating_minimization(starts, [[] for _ in starts], disjunctive_cuts_type)
+        Xs = [a["U"] @ a["V"] for a in ams]
+        objs = np.atleast_1d(engine.evaluate_objective(np.stack(Xs)))
+        X0 = Xs[int(np.argmin(objs))]
     else:
         X0 = U0 @ (U0.T @ A0)
     Us, _, _ = np.linalg.svd(X0, full_matrices=False)

@@ -386,7 +386,8 @@ def test_branch_and_bound_invariants(have_gpu, omc, orc):
     bound that the oracle confirms."""
     A, mask = orc.make_instance(20, 24, 1, seed=11, kind="readme")
     eng = omc.Engine(A, mask, GAMMA, 1)
-    sol, inst = omc.pkg.bnb.branch_and_bound(eng, A, mask, gap=1e-3, time_limit=60.0, batch=16, rho_scale=16.0, use_max_steps=True, max_steps=150)
+    sol, inst = omc.pkg.bnb.branch_and_bound(eng, A, mask, gap=1e-3, time_limit=60.0, batch=16, rho_scale=16.0, use_max_steps=True, max_steps=150,
+                                             altmin_root_n_iters=3)
     log = np.array(inst["run_log"]); c = inst["run_details"]
     assert len(log) >= 2
     lbs, ubs = log[:, 3], log[:, 4]
