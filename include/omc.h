@@ -73,7 +73,7 @@ typedef struct omc_relax_params {
   int reference_quirk_q1; /* 1: linear3/right piece exactly as OMC.jl:1675; 0: secant        (1)     */
   int breakpoints;     /* OMC_SMALLEST_1_EIGVEC / _2_ : which separation vector to return    (1)     */
   int stall_checks;    /* stop with OMC_SLOW_PROGRESS after this many stationary checks      (8)     */
-  int bump_max;        /* penalty bumps per node (0 = off): rho *= bump_factor when the primal   (6)     */
+  int bump_max;        /* penalty bumps per node (0 = off): rho *= bump_factor when the primal   (2)     */
   double bump_ratio;   /*   residual exceeds bump_ratio x the dual residual at a check ...      (4.0)   */
   double bump_factor;  /*                                                                       (4.0)   */
   int bump_after;      /*   ... from this iteration on, at least bump_window checks apart       (100)   */

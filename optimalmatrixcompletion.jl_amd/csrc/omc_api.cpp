@@ -102,7 +102,7 @@ void omc_relax_params_default(omc_relax_params* p) {
   p->eps_gap = 1e-6; p->eps_feas = 1e-7; p->max_iters = 3000; p->check_every = 25;
   p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
-  p->bump_max = 6; p->bump_ratio = 4.0; p->bump_factor = 4.0; p->bump_after = 100; p->bump_window = 4; p->slots = 0;
+  p->bump_max = 2; p->bump_ratio = 4.0; p->bump_factor = 4.0; p->bump_after = 100; p->bump_window = 4; p->slots = 0;
   p->accel = 0; p->aa_mem = 10; p->aa_every = 5; p->aa_start = 50; p->aa_reg = 1e-10; p->aa_safeguard = 1.0;
 }
 

@@ -456,7 +456,7 @@ class RelaxParams:
     bump_factor: float = 4.0
     bump_window: int = 4         # checks between two bumps
     bump_after: int = 100        # first iteration at which a bump may happen
-    bump_max: int = 6
+    bump_max: int = 2            # more than two bumps (x16) over-penalise deep nodes: measured on config 2, depth 9 (tools/gpu_bump2.py)
     bump_ratio: float = 4.0
     # Anderson acceleration (type II) of the fixed-point map, mirrored by k_aa in omc_device.hip
     accel: int = 0               # off by default (helps small / ill-conditioned nodes, not config 2)
