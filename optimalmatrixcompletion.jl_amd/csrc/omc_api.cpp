@@ -912,6 +912,12 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
 // generate_violated_Shor_minors (OMC.jl:2614-2640).  Kernels in omc_shor.hip; the host only sequences the segments.
 // ---------------------------------------------------------------------------------------------------------------------
 struct ShorSeg { int kind, la, lb; };
+// two timing events that are destroyed on every exit path
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int create() { if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1; return 0; }
+  ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
 static void shor_segments(int n_classes, const int* classes, bool dedup, std::vector<ShorSeg>& segs) {
   bool seen[5] = {false, false, false, false, false};
   for (int c = 0; c < n_classes; ++c) {
@@ -984,8 +990,9 @@ int omc_shor_indexes(omc_instance* h, int n_classes, const int* num_entries_pres
   *count = total;
   if (!out || capacity < total || total == 0) return 0;      // size query (or nothing to write)
   if ((rc = h->sout.ensure((size_t)total * 32))) return rc;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  EventPair ev;
+  if (ev.create()) return fail(999, "hipEventCreate failed");
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   HIPCHK(hipEventRecord(e0, h->stream));
   long long base = 0;
   for (size_t q = 0; q < segs.size(); ++q) {
@@ -1001,7 +1008,6 @@ int omc_shor_indexes(omc_instance* h, int n_classes, const int* num_entries_pres
   HIPCHK(hipStreamSynchronize(h->stream));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   h->shor_last_ms = ms; h->shor_last_candidates = total;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 0;
 }
 
@@ -1032,8 +1038,9 @@ int omc_violated_shor_minors(omc_instance* h, const double* X, int n_classes, co
   if ((rc = upload(h->bXin, X, sizeof(double) * (size_t)k * n * m, h->stream))) return rc;
   if ((rc = h->shi.ensure((size_t)N * 8)) || (rc = h->slo.ensure((size_t)N * 8))) return rc;
   HIPCHK(hipMemsetAsync(h->scnt.p, 0, 16, h->stream));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  EventPair ev;
+  if (ev.create()) return fail(999, "hipEventCreate failed");
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   HIPCHK(hipEventRecord(e0, h->stream));
   long long base = 0;
   for (size_t q = 0; q < segs.size(); ++q) {
@@ -1097,7 +1104,6 @@ int omc_violated_shor_minors(omc_instance* h, const double* X, int n_classes, co
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     h->shor_last_ms = ms; h->shor_last_candidates = N;
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *n_out = (int)K;
   return 0;
 }
