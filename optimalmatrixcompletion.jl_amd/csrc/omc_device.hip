@@ -281,7 +281,6 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
   auto vo = Lm + tri;
   auto pinv = vo + c;
   auto sidx = (int*)(pinv + c);
-  const int G = WAVE / c, r = lane / G, g = lane - r * G, rb = tri_i(r, 0);
   const double gm = w.gamma;
   const double* Y = w.Y + (size_t)b * n * n;
   const double* Yp = w.Yp + (size_t)b * n * n;
@@ -292,16 +291,34 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
   WAVE_SYNC();
   const double rho_f = w.rho_b[b] * w.rho_f_ratio;
   const double coef = (mode == 0) ? gm / (2.0 * rho_f) : 0.0;
-  if (r < c) {
-    const int ir = sidx[r];
-    const double cr = coef * vo[r];
+  {
+    // gather of the packed lower triangle: flat index e = r (r + 1) / 2 + q over all 64 lanes, four entries per trip with every
+    // global load issued before the first use (unguarded, clamped addresses), so that the L2 latencies overlap
     auto dst = (mode == 0) ? Bm : Lm;
-    for (int q = g; q <= r; q += G) {
-      const size_t a = (size_t)sidx[q] * n + ir;
-      const double yv = (mode == 0) ? (2.0 * Y[a] - Yp[a]) : Y[a];
-      double v = gm * (yv - cr * vo[q]);
-      if (q == r) v += 1.0;
-      dst[rb + q] = v;
+    for (int e0 = lane; e0 < tri; e0 += 4 * WAVE) {
+      int rr[4], qq[4]; bool vv[4]; double y1[4], y2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * WAVE;
+        vv[u] = e < tri;
+        const int ec = vv[u] ? e : 0;
+        int ri = (int)((__builtin_sqrtf(8.0f * (float)ec + 1.0f) - 1.0f) * 0.5f);
+        while (tri_i(ri, 0) > ec) --ri;
+        while (tri_i(ri + 1, 0) <= ec) ++ri;
+        rr[u] = ri; qq[u] = ec - tri_i(ri, 0);
+        const size_t a = (size_t)sidx[qq[u]] * n + sidx[ri];
+        y1[u] = Y[a];
+        y2[u] = (mode == 0) ? Yp[a] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (vv[u]) {
+          const double yv = (mode == 0) ? (2.0 * y1[u] - y2[u]) : y1[u];
+          double v = gm * (yv - coef * vo[rr[u]] * vo[qq[u]]);
+          if (rr[u] == qq[u]) v += 1.0;
+          dst[e0 + u * WAVE] = v;
+        }
+      }
     }
   }
   const int my = (lane < c) ? sidx[lane] : 0;
@@ -318,9 +335,9 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
     for (int it = 0; it < 60; ++it) {
       ++nfact_;
       WAVE_SYNC();
-      if (r < c) for (int q = g; q <= r; q += G) Lm[rb + q] = Bm[rb + q] + ((q == r) ? cp * s : 0.0);
+      { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; }
       WSTAMP(22);
-      const bool ok_ = wave_ldl(Lm, pinv, c, r, g, G, lane);
+      const bool ok_ = wave_ldl(Lm, pinv, c, lane);
       WSTAMP(23);
       if (!ok_) {  // s below the positive definite range: move right
         lo = s; lo_valid = false;
@@ -350,8 +367,8 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
         {  // accuracy audit of the Taylor finish: re-factor at the accepted s and compare (diag 6 = max relative error of
            // alpha, diag 7 = max |phi(s)| / s)
           WAVE_SYNC();
-          if (r < c) for (int q = g; q <= r; q += G) Lm[rb + q] = Bm[rb + q] + ((q == r) ? cp * s : 0.0);
-          wave_ldl(Lm, pinv, c, r, g, G, lane);
+          { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; }
+          wave_ldl(Lm, pinv, c, lane);
           const double ye = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
           double e1 = fabs(ye - yr), e2 = fabs(ye);
           for (int o = 32; o > 0; o >>= 1) { e1 = fmax(e1, __shfl_xor(e1, o, WAVE)); e2 = fmax(e2, __shfl_xor(e2, o, WAVE)); }
@@ -371,8 +388,8 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
     if (!fin) {
       ++nfact_;
       WAVE_SYNC();
-      if (r < c) for (int q = g; q <= r; q += G) Lm[rb + q] = Bm[rb + q] + ((q == r) ? cp * s : 0.0);
-      wave_ldl(Lm, pinv, c, r, g, G, lane);
+      { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; }
+      wave_ldl(Lm, pinv, c, lane);
       yr = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
     }
     if (lane == 0) w.sval[(size_t)b * w.m + j] = s;
@@ -381,7 +398,7 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
     if (lane < c) { alpha[lane] = yr; lamD[my] = yr; }
     WSTAMP(27);
   } else {
-    if (!wave_ldl(Lm, pinv, c, r, g, G, lane)) {  // Y not PSD enough on this block: report +inf objective contribution
+    if (!wave_ldl(Lm, pinv, c, lane)) {  // Y not PSD enough on this block: report +inf objective contribution
       if (lane == 0) atomicAdd(&w.obj[b], 1e300);
       return;
     }

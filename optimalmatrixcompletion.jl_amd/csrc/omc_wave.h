@@ -118,30 +118,58 @@ __device__ __forceinline__ double fast_rcp(double p) {
   x = fma(fma(-p, x, 1.0), x, x);
   return x;
 }
+// Register-panel version: lane r owns row r.  Panels of 8 columns are factorised entirely in registers (each lane holds its 8
+// panel entries; pivots and pivot-column entries of other rows arrive by v_readlane, so no LDS traffic and no barrier), then every
+// trailing column q gets its rank-8 update  L(r,q) -= sum_j L(r,kb+j) L~(q,kb+j)  with the eight L~(q,.) broadcast by v_readlane:
+// one LDS read-modify-write per (row, column, panel) instead of one per (row, column, pivot).  No cross-lane LDS communication at
+// all, hence a single wave sync at the end.  On exit Lm(r,q) = L(r,q) d_q below the diagonal, Lm(q,q) = d_q, pinv[q] = 1/d_q.
 template <class PT>
-__device__ __forceinline__ bool wave_ldl(PT Lm, PT pinv, int c, int r, int g, int G, int lane) {
-  const int rb = tri_i(r, 0);
-  for (int kk = 0; kk < c; ++kk) {
-    WAVE_SYNC();
-    const double piv = Lm[tri_i(kk, kk)];
-    if (!(piv > 1e-290)) return false;      // not positive definite (also keeps fast_rcp in its normal range)
-    const double pi_ = fast_rcp(piv);
-    if (lane == 0) pinv[kk] = pi_;
-    if (r > kk && r < c) {
-      const double ark = Lm[rb + kk] * pi_;
-      // four entries per trip, all loads before the stores, so that the LDS latencies overlap
-      for (int q0 = kk + 1 + g; q0 <= r; q0 += 4 * G) {
-        const int q1 = q0 + G, q2 = q1 + G, q3 = q2 + G;
-        const bool v1 = q1 <= r, v2 = q2 <= r, v3 = q3 <= r;
-        const double a0 = Lm[rb + q0], c0 = Lm[tri_i(q0, kk)];
-        const double a1 = v1 ? Lm[rb + q1] : 0.0, c1 = v1 ? Lm[tri_i(q1, kk)] : 0.0;
-        const double a2 = v2 ? Lm[rb + q2] : 0.0, c2 = v2 ? Lm[tri_i(q2, kk)] : 0.0;
-        const double a3 = v3 ? Lm[rb + q3] : 0.0, c3 = v3 ? Lm[tri_i(q3, kk)] : 0.0;
-        Lm[rb + q0] = fma(-ark, c0, a0);
-        if (v1) Lm[rb + q1] = fma(-ark, c1, a1);
-        if (v2) Lm[rb + q2] = fma(-ark, c2, a2);
-        if (v3) Lm[rb + q3] = fma(-ark, c3, a3);
+__device__ __forceinline__ bool wave_ldl(PT Lm, PT pinv, int c, int lane) {
+  const bool mine = lane < c;
+  const int rb = tri_i(mine ? lane : 0, 0);
+  WAVE_SYNC();
+  for (int kb = 0; kb < c; kb += 8) {
+    const int nb = (c - kb < 8) ? (c - kb) : 8;
+    double P[8], pis[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool v = mine && (kb + j <= lane);
+      const double x = Lm[rb + (v ? kb + j : 0)];      // clamped address, never a guarded load
+      P[j] = v ? x : 0.0;
+      pis[j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < nb) {                                    // wave-uniform
+        const double piv = readlane_d(P[j], kb + j);
+        if (!(piv > 1e-290)) return false;             // not positive definite (also keeps fast_rcp in its normal range)
+        const double pi_ = fast_rcp(piv);
+        pis[j] = pi_;
+        const double lr = P[j] * pi_;                  // unit-lower entry L(r, kb+j) for the rows below the pivot
+#pragma unroll
+        for (int j2 = j + 1; j2 < 8; ++j2) {
+          if (j2 < nb) {
+            const double lq = readlane_d(P[j], kb + j2);
+            if (lane >= kb + j2) P[j2] = fma(-lr, lq, P[j2]);
+          }
+        }
       }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < nb) {
+        if (mine && lane >= kb + j) Lm[rb + kb + j] = P[j];
+        if (lane == j) pinv[kb + j] = pis[j];
+      }
+    }
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = P[j] * pis[j];
+    for (int q = kb + nb; q < c; ++q) {                // wave-uniform loop over the trailing columns
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fma(a[j], readlane_d(P[j], q), acc);
+      if (mine && lane >= q) Lm[rb + q] -= acc;
     }
   }
   WAVE_SYNC();
