@@ -506,8 +506,9 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   {
     const int c_lds = std::min(h->cmax, 64);
     w.cp_lds_c = c_lds;
-    w.cp_lds_doubles = c_lds * c_lds + 5 * c_lds + 8;
-    if ((size_t)4 * w.cp_lds_doubles * 8 > OMC_MAX_DYN_LDS) { w.cp_lds_c = 48; w.cp_lds_doubles = 48 * 48 + 5 * 48 + 8; }
+    w.cp_keepB = (c_lds <= 40 || getenv("OMC_COLPROX_KEEPB")) ? 1 : 0;
+    w.cp_lds_doubles = w.cp_keepB ? c_lds * c_lds + 5 * c_lds + 8 : c_lds * (c_lds + 1) / 2 + 4 * c_lds + 8;
+    if ((size_t)4 * w.cp_lds_doubles * 8 > OMC_MAX_DYN_LDS) { w.cp_lds_c = 48; w.cp_lds_doubles = 48 * 48 + 5 * 48 + 8; w.cp_keepB = 1; }
     if (h->cmax > w.cp_lds_c) {
       w.cp_scratch_stride = (size_t)h->cmax * h->cmax + 5 * (size_t)h->cmax + 8;
       ENS(h->bcp, sB * m * w.cp_scratch_stride * 8);

@@ -80,7 +80,7 @@ struct OmcWS {
   int *done, *status, *iters, *sweeps, *stall;
   // scratch
   double* cp_scratch;  size_t cp_scratch_stride;   // per wave (B*m waves) when a column is too large for LDS
-  int cp_lds_c; int cp_lds_doubles;
+  int cp_lds_c; int cp_lds_doubles; int cp_keepB;   // cp_keepB = 0: dense columns, B is gathered again instead of kept in LDS
   double* cone_scratch; size_t cone_scratch_stride; // per node when N is too large for LDS
   double* glob_scratch; size_t glob_scratch_stride;
   double* small_scratch; size_t small_scratch_stride;

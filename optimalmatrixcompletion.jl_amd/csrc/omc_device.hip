@@ -276,8 +276,11 @@ template <class PT>
 __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int j, int off, int c, int lane, PT base) {
   const int n = w.n;
   const int tri = (c * (c + 1)) >> 1;
+  // dense instances (columns with more than 40 observed rows): B is not kept beside L -- a second factorization gathers it again from
+  // L2 -- which halves the LDS per wave and doubles the waves per CU
+  const bool keepB = w.cp_keepB != 0;
   auto Bm = base;
-  auto Lm = Bm + tri;
+  auto Lm = keepB ? Bm + tri : base;
   auto vo = Lm + tri;
   auto pinv = vo + c;
   auto sidx = (int*)(pinv + c);
@@ -291,10 +294,9 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
   WAVE_SYNC();
   const double rho_f = w.rho_b[b] * w.rho_f_ratio;
   const double coef = (mode == 0) ? gm / (2.0 * rho_f) : 0.0;
-  {
+  auto gather = [&](decltype(Lm) dst, double diag_shift) {
     // gather of the packed lower triangle: flat index e = r (r + 1) / 2 + q over all 64 lanes, four entries per trip with every
     // global load issued before the first use (unguarded, clamped addresses), so that the L2 latencies overlap
-    auto dst = (mode == 0) ? Bm : Lm;
     for (int e0 = lane; e0 < tri; e0 += 4 * WAVE) {
       int rr[4], qq[4]; bool vv[4]; double y1[4], y2[4];
 #pragma unroll
@@ -315,12 +317,13 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
         if (vv[u]) {
           const double yv = (mode == 0) ? (2.0 * y1[u] - y2[u]) : y1[u];
           double v = gm * (yv - coef * vo[rr[u]] * vo[qq[u]]);
-          if (rr[u] == qq[u]) v += 1.0;
+          if (rr[u] == qq[u]) v += 1.0 + diag_shift;
           dst[e0 + u * WAVE] = v;
         }
       }
     }
-  }
+  };
+  gather((mode == 0 && keepB) ? Bm : Lm, 0.0);
   const int my = (lane < c) ? sidx[lane] : 0;
   WSTAMP(21);
   if (mode == 0) {
@@ -331,11 +334,12 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
     bool lo_valid = false;       // the factorization succeeded at lo and phi(lo) >= 0
     double yr = 0.0;
     bool fin = false;
+    bool first_ = true;      // without the copy of B: L still holds the gathered B for the first factorization
     int nfact_ = 0; (void)nfact_;
     for (int it = 0; it < 60; ++it) {
       ++nfact_;
       WAVE_SYNC();
-      { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; }
+      { if (keepB) { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; } else if (first_) { WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; } else gather(Lm, cp * s); first_ = false; }
       WSTAMP(22);
       const bool ok_ = wave_ldl(Lm, pinv, c, lane);
       WSTAMP(23);
@@ -367,7 +371,7 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
         {  // accuracy audit of the Taylor finish: re-factor at the accepted s and compare (diag 6 = max relative error of
            // alpha, diag 7 = max |phi(s)| / s)
           WAVE_SYNC();
-          { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; }
+          { if (keepB) { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; } else if (first_) { WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; } else gather(Lm, cp * s); first_ = false; }
           wave_ldl(Lm, pinv, c, lane);
           const double ye = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
           double e1 = fabs(ye - yr), e2 = fabs(ye);
@@ -388,7 +392,7 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
     if (!fin) {
       ++nfact_;
       WAVE_SYNC();
-      { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; }
+      { if (keepB) { for (int e = lane; e < tri; e += WAVE) Lm[e] = Bm[e]; WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; } else if (first_) { WAVE_SYNC(); if (lane < c) Lm[tri_i(lane, lane)] += cp * s; } else gather(Lm, cp * s); first_ = false; }
       wave_ldl(Lm, pinv, c, lane);
       yr = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
     }

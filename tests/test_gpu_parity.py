@@ -237,6 +237,18 @@ def test_dense_columns_and_deep_paths(have_gpu, omc, orc):
     r = orc.sdp_relaxation(inst, params=orc.RelaxParams(rho_scale=8.0), want_certificate=False)
     assert g["status_code"] == r["termination_status"] and g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
     eng.close()
+    # columns with 41..64 observed rows: the layout without a copy of B (a second factorization gathers B again)
+    n, m, k = 56, 60, 1
+    A = rng.standard_normal((n, 1)) @ rng.standard_normal((1, m)) + 0.05 * rng.standard_normal((n, m))
+    mask = rng.random((n, m)) < 0.9
+    inst = orc.Instance(A, mask, GAMMA, k)
+    assert 40 < max(len(c) for c in inst.cols) <= 64
+    eng = omc.Engine(A, mask, GAMMA, k)
+    g = eng.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=8.0))[0]
+    r = orc.sdp_relaxation(inst, params=orc.RelaxParams(rho_scale=8.0), want_certificate=False)
+    assert g["status_code"] == r["termination_status"] == 0 and g["iters"] == r["iters"]
+    assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
+    eng.close()
     # deep path
     n, m = 20, 24
     A, mask = orc.make_instance(n, m, 1, seed=51, kind="readme")
