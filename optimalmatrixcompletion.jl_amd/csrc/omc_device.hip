@@ -830,8 +830,8 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
 // ---------------------------------------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
 
-template <int LPP, bool USE_LDS, int RPL2>   // RPL2 = rows per lane / 2 as a compile-time constant (0: run-time bound)
-__global__ void __launch_bounds__(512) k_cone_ws(OmcWS w) {
+template <int LPP, bool USE_LDS, int RPL2, int TPB = 512>   // RPL2 = rows per lane / 2 as a compile-time constant (0: run-time bound)
+__global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   extern __shared__ double smem[];
   __shared__ int s_nsel;
   __shared__ double s_base;
@@ -1868,7 +1868,10 @@ void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, 
     else if (lpp == 8) launch_ws_lds<8>(w, rpl2, lds_bytes, s);
     else launch_ws_lds<4>(w, rpl2, lds_bytes, s);
   } else {
-    hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->nB), dim3(512), 0, s, *w);
+    // L2-resident G (n > 144): 1024 threads = 64 pair groups halve the passes per step (the kernel is bound by L2 latency there)
+    if (rpl2 == 7 && !getenv("OMC_CONE_512")) hipLaunchKernelGGL((k_cone_ws<16, false, 7, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
+    else if (rpl2 == 8 && !getenv("OMC_CONE_512")) hipLaunchKernelGGL((k_cone_ws<16, false, 8, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
+    else hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->nB), dim3(512), 0, s, *w);
   }
 }
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
