@@ -459,3 +459,23 @@ def test_time_limit_and_iteration_cap_statuses(have_gpu, omc, orc):
         assert o["termination_status"] == "TIME_LIMIT" and o["feasible"]
         assert o["dual_bound"] <= full["objective"] * (1 + 1e-9)
     eng.close()
+
+
+def test_order_200_l2_resident_variants_agree(have_gpu, omc):
+    """BASELINE config 3 size (200 x 200): the 1024-thread launch of the L2-resident cone kernel against its 512-thread form
+    (same arithmetic, different lane mapping), plus the certificate properties of the truncated solve."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(3, seed=0)
+    eng = omc.Engine(A, mask, gamma, c["k"])
+    P = omc.default_params(rho_scale=4.0, max_iters=125)
+    a = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P, want_X=False)[0]
+    os.environ["OMC_CONE_512"] = "1"
+    try:
+        b = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P, want_X=False)[0]
+    finally:
+        del os.environ["OMC_CONE_512"]
+    assert a["iters"] == b["iters"] and a["status_code"] == b["status_code"]
+    assert a["objective"] == pytest.approx(b["objective"], rel=1e-10) and a["dual_bound"] == pytest.approx(b["dual_bound"], rel=1e-8)
+    assert a["dual_bound"] <= a["objective"] * (1 + 1e-6)
+    w = np.linalg.eigvalsh(a["Y"])
+    assert w[0] >= -1e-5 and w[-1] <= 1 + 1e-5
+    eng.close()
