@@ -85,6 +85,8 @@ typedef struct omc_relax_params {
   int aa_start;        /*   first iteration that records history                                     (50)    */
   double aa_reg;       /*   Tikhonov weight of the least squares, relative to mean diag              (1e-10) */
   double aa_safeguard; /*   the point is kept when the next fixed-point residual <= this x the last  (1.0)   */
+  int first_wins;      /* 1: the batch ends at the first check at which some node is OPTIMAL; the others are
+                          returned as they stand (SLOW_PROGRESS, values available).  Penalty autotune.  (0)     */
 } omc_relax_params;
 
 void omc_relax_params_default(omc_relax_params* p);

@@ -32,18 +32,19 @@ def make_children(cuts, relax_result, cut_type, k):
     return [list(cuts) + [(x, U, d)] for d in child_directions(cut_type, k)]
 
 
-def autotune_rho_scale(engine, cut_type="linear", scales=(0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0), max_iters=600, **params):
+def autotune_rho_scale(engine, cut_type="linear", scales=(0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0, 32.0), max_iters=600, return_result=False, **params):
     """Relax the root once per candidate penalty -- all candidates in ONE GPU batch (per-node penalties) -- and keep the
-    scale that certifies the gap in the fewest iterations.  Returns (scale, log, root_result_of_the_winner)."""
+    scale that certifies the gap in the fewest iterations; the batch ends as soon as the first candidate is certified
+    (`first_wins`).  Returns (scale, log) or, with return_result, (scale, log, root result of the winner)."""
     from .api import default_params
-    p = default_params(rho_scale=1.0, max_iters=max_iters, **params)
+    p = default_params(rho_scale=1.0, max_iters=max_iters, first_wins=1, **params)
     outs = engine.matrix_completion_SDP_relaxation([[] for _ in scales], cut_type, params=p, rho_scales=list(scales))
     log = [(float(sc), o["status_code"], o["iters"]) for sc, o in zip(scales, outs)]
     ok = [(o["iters"], i) for i, o in enumerate(outs) if o["status_code"] == 0]
     if not ok:
-        return 1.0, log
+        return (1.0, log, None) if return_result else (1.0, log)
     _, i = min(ok)
-    return float(scales[i]), log
+    return (float(scales[i]), log, outs[i]) if return_result else (float(scales[i]), log)
 
 
 def expand_frontier(engine, depth, cut_type="linear", params=None, max_nodes=None):
@@ -151,8 +152,12 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     solution.update(objective_initial=ub, objective_initial_time_found=time.time() - start, X_initial=X0, U_initial=U_init,
                     Y_initial=U_init @ U_init.T, MSE_in_initial=mse0["in"], MSE_out_initial=mse0["out"], MSE_all_initial=mse0["all"],
                     objective=ub, X=X0, U=U_init, Y=U_init @ U_init.T, objective_time_found=time.time() - start)   # OMC.jl:604-621
+    precomputed = {}
     if rho_scale is None:
-        rho_scale, _ = autotune_rho_scale(engine, disjunctive_cuts_type)
+        rho_scale, _, root_res = autotune_rho_scale(engine, disjunctive_cuts_type, return_result=True,
+                                                    breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints])
+        if root_res is not None and params is None:
+            precomputed[1] = root_res                      # the winner of the autotune batch IS the root relaxation
     P = params or default_params(rho_scale=float(rho_scale), breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints])
     # ---- tree ------------------------------------------------------------------------------------------------
     nodes = {1: dict(cuts=[], LB=-math.inf, depth=0, parent=0)}
@@ -206,8 +211,11 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
         if todo:
             t0 = time.time()
             mine = todo[rank::world_size] if world_size > 1 else todo
-            res_mine = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in mine], disjunctive_cuts_type, params=P,
-                                                               want_X=True) if mine else []
+            need = [(nid, nd) for nid, nd in mine if nid not in precomputed]
+            fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=P,
+                                                            want_X=True) if need else []
+            fresh = {nid: r for (nid, _), r in zip(need, fresh)}
+            res_mine = [precomputed.pop(nid) if nid in precomputed else fresh[nid] for nid, _ in mine]
             if world_size > 1:
                 import torch.distributed as dist
                 gathered = [None] * world_size

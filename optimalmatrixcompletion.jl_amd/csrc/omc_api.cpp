@@ -103,7 +103,7 @@ void omc_relax_params_default(omc_relax_params* p) {
   p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
   p->bump_max = 2; p->bump_ratio = 4.0; p->bump_factor = 4.0; p->bump_after = 100; p->bump_window = 4; p->slots = 0;
-  p->accel = 0; p->aa_mem = 10; p->aa_every = 5; p->aa_start = 50; p->aa_reg = 1e-10; p->aa_safeguard = 1.0;
+  p->accel = 0; p->aa_mem = 10; p->aa_every = 5; p->aa_start = 50; p->aa_reg = 1e-10; p->aa_safeguard = 1.0; p->first_wins = 0;
 }
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
@@ -667,6 +667,28 @@ int omc_relax_solve(omc_instance* h) {
     });
     HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * S, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (P.first_wins) {   // the first certified node ends the batch (penalty autotune): everything still running is harvested as it stands
+      std::vector<int> stv(S);
+      HIPCHK(hipMemcpyAsync(stv.data(), w.status, sizeof(int) * S, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      bool won = false;
+      for (int b = 0; b < S; ++b) if (node_of[b] >= 0 && done[b] && stv[b] == OMC_ST_OPTIMAL) won = true;
+      if (won) {
+        for (int b = 0; b < S; ++b) done[b] = 1;
+        HIPCHK(hipMemcpyAsync(w.done, done.data(), sizeof(int) * S, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (next < Btot) {   // nodes that never got a slot
+          std::vector<int> st(Btot - next, OMC_ST_SLOW), itz(Btot - next, 0);
+          std::vector<double> inf(Btot - next, 1e300), ninf(Btot - next, -1e300);
+          HIPCHK(hipMemcpyAsync(w.ostatus + next, st.data(), sizeof(int) * st.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(w.oiters + next, itz.data(), sizeof(int) * itz.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(w.oobj + next, inf.data(), 8 * inf.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(w.olb + next, ninf.data(), 8 * ninf.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipStreamSynchronize(s));
+          next = Btot;
+        }
+      }
+    }
     // harvest finished slots, hand them the next pending nodes
     std::vector<int> init(S, 0), fin(S, 0);
     int nfin = 0;

@@ -454,6 +454,13 @@ def test_time_limit_and_iteration_cap_statuses(have_gpu, omc, orc):
     capped = eng.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=4.0, max_iters=50))[0]
     assert capped["termination_status"] == "SLOW_PROGRESS" and capped["feasible"] and capped["iters"] == 50
     assert capped["dual_bound"] <= full["objective"] * (1 + 1e-9)                       # still a valid lower bound
+    # first_wins (penalty autotune): the batch ends at the first check with a certified node; the others come back as they stand
+    race = eng.matrix_completion_SDP_relaxation([[], [], []], "linear", params=omc.default_params(rho_scale=1.0, first_wins=1), rho_scales=[0.05, 4.0, 300.0])
+    assert race[1]["status_code"] == 0 and race[1]["iters"] == full["iters"]
+    for o in (race[0], race[2]):
+        assert o["status_code"] in (0, 1) and o["iters"] <= race[1]["iters"] and o["feasible"]
+        assert o["dual_bound"] <= full["objective"] * (1 + 1e-9)
+    assert race[0]["status_code"] == 1 or race[2]["status_code"] == 1
     timed = eng.matrix_completion_SDP_relaxation([[], []], "linear", params=omc.default_params(rho_scale=4.0, time_limit=1e-9))
     for o in timed:
         assert o["termination_status"] == "TIME_LIMIT" and o["feasible"]
