@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--depth", type=int, default=int(os.environ.get("OMC_BENCH_DEPTH", 11)), help="frontier depth: 2^depth nodes per GPU per step")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("OMC_BENCH_SLOTS", 2048)), help="nodes relaxed concurrently per GPU (continuous batching)")
     ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--accel", type=int, default=int(os.environ.get("OMC_BENCH_ACCEL", 0)), help="1: Anderson acceleration of the ADMM map (library default 0)")
     ap.add_argument("--cpu-nodes", type=int, default=2, help="nodes relaxed by the CPU oracle for cpu_baseline (rank 0, N=1 only)")
     args = ap.parse_args()
 
@@ -50,7 +51,7 @@ def main():
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
     eng = omc_amd.Engine(A, mask, gamma, k, device=local)
     rho_scale, tune_log = bnb.autotune_rho_scale(eng, cfg["cut_type"])
-    P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots)
+    P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel)
     # every rank builds the same frontier (deterministic) and keeps a shard-sized batch: rank r takes a rotated copy so
     # that ranks do not all hold the identical node order
     nodes, _ = bnb.expand_frontier(eng, args.depth, cfg["cut_type"], params=P)

@@ -98,7 +98,7 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                      altmin_flag=True, max_altmin_probability=1.0, min_altmin_probability=0.005,
                      altmin_probability_decay_rate=1.1, use_max_steps=False, max_steps=1000000, time_limit=3600.0,
                      batch=64, rho_scale=None, params=None, seed=0, use_certified_bound=True, verbose=False,
-                     rank=0, world_size=1, altmin_root_n_iters=1):
+                     rank=0, world_size=1, altmin_root_n_iters=1, accel=1):
     """Behavioural counterpart of the reference driver for use_disjunctive_cuts = true, no Shor, one altmin run at the
     root (altmin_root_n_iters = 1).  Differences, all deliberate: (1) up to `batch` nodes are popped per round in the
     reference's selection order and relaxed in ONE GPU batch (batch=1 reproduces the serial order); (2) the node bound
@@ -158,7 +158,9 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                                                     breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints])
         if root_res is not None and params is None:
             precomputed[1] = root_res                      # the winner of the autotune batch IS the root relaxation
-    P = params or default_params(rho_scale=float(rho_scale), breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints])
+    # Anderson acceleration is ON in the driver: on trees that really branch it halves the iterations per node (README instance: 263 -> 407
+    # nodes/s, tools/gpu_bnb_cfg1.py); the library default stays off because the degenerate frontier of the bench instance rejects most points
+    P = params or default_params(rho_scale=float(rho_scale), breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints], accel=int(accel))
     # ---- tree ------------------------------------------------------------------------------------------------
     nodes = {1: dict(cuts=[], LB=-math.inf, depth=0, parent=0)}
     heap = [(math.inf, 1)]            # (key = parent objective, node id)   OMC.jl:697

@@ -8,11 +8,13 @@ rs, log = omc_amd.pkg.bnb.autotune_rho_scale(eng, "linear"); print("autotune", r
 P = omc_amd.default_params(rho_scale=rs)
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 t0 = time.perf_counter(); nodes, levels = omc_amd.pkg.bnb.expand_frontier(eng, depth, "linear", params=P); print("frontier", len(nodes), "%.1fs" % (time.perf_counter() - t0), flush=True)
-P = omc_amd.default_params(rho_scale=rs, slots=len(nodes))
-t0 = time.perf_counter()
-out = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_Y=False, want_X=False)
-el = time.perf_counter() - t0
-it = np.array([o["iters"] for o in out]); st = np.bincount([o["status_code"] for o in out], minlength=4)
-lm = np.array([o["lambda_min"][0] for o in out])
-print("README-type 100x100: %d nodes in %.2fs = %.1f node-relaxations/s; status %s; iters median %d mean %.0f; lambda_min(UU'-Y) median %.3f; kernel ms %s" % (
-    len(nodes), el, len(nodes) / el, st, np.median(it), it.mean(), np.median(lm), {k: round(v["ms"]) for k, v in eng.kernel_stats().items()}))
+for acc in ([0, 1] if os.environ.get("ACCEL_TOO") else [0]):
+  P = omc_amd.default_params(rho_scale=rs, slots=len(nodes), accel=acc)
+  t0 = time.perf_counter()
+  out = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_Y=False, want_X=False)
+  el = time.perf_counter() - t0
+  print("accel", acc, end=" ")
+  it = np.array([o["iters"] for o in out]); st = np.bincount([o["status_code"] for o in out], minlength=4)
+  lm = np.array([o["lambda_min"][0] for o in out])
+  print("README-type 100x100: %d nodes in %.2fs = %.1f node-relaxations/s; status %s; iters median %d mean %.0f; lambda_min(UU'-Y) median %.3f; kernel ms %s" % (
+      len(nodes), el, len(nodes) / el, st, np.median(it), it.mean(), np.median(lm), {k: round(v["ms"]) for k, v in eng.kernel_stats().items()}))
