@@ -81,7 +81,7 @@ typedef struct omc_relax_params {
   int slots;           /* nodes relaxed concurrently (continuous batching); 0 = min(B, 256)       (0)     */
   int accel;           /* 1: Anderson acceleration of the ADMM fixed-point map (type II, safeguarded) (0)  */
   int aa_mem;          /*   differences kept (<= 10)                                                 (10)    */
-  int aa_every;        /*   an extrapolated point every this many iterations                         (5)     */
+  int aa_every;        /*   an extrapolated point every this many iterations                         (10)    */
   int aa_start;        /*   first iteration that records history                                     (50)    */
   double aa_reg;       /*   Tikhonov weight of the least squares, relative to mean diag              (1e-10) */
   double aa_safeguard; /*   the point is kept when the next fixed-point residual <= this x the last  (1.0)   */

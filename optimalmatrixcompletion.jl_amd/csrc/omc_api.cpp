@@ -103,7 +103,7 @@ void omc_relax_params_default(omc_relax_params* p) {
   p->rho_scale = 1.0; p->rho_f_ratio = 0.1; p->relax = 1.6; p->time_limit = 3600.0;
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
   p->bump_max = 2; p->bump_ratio = 4.0; p->bump_factor = 4.0; p->bump_after = 100; p->bump_window = 4; p->slots = 0;
-  p->accel = 0; p->aa_mem = 10; p->aa_every = 5; p->aa_start = 50; p->aa_reg = 1e-10; p->aa_safeguard = 1.0; p->first_wins = 0;
+  p->accel = 0; p->aa_mem = 10; p->aa_every = 10; p->aa_start = 50; p->aa_reg = 1e-10; p->aa_safeguard = 1.0; p->first_wins = 0;
 }
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {

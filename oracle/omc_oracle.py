@@ -461,7 +461,7 @@ class RelaxParams:
     # Anderson acceleration (type II) of the fixed-point map, mirrored by k_aa in omc_device.hip
     accel: int = 0               # off by default (helps small / ill-conditioned nodes, not config 2)
     aa_mem: int = 10             # residual differences kept
-    aa_every: int = 5            # an extrapolated point every this many iterations ...
+    aa_every: int = 10           # an extrapolated point every this many iterations ...
     aa_start: int = 50           # ... from this iteration on
     aa_reg: float = 1e-10        # Tikhonov weight of the normal equations, relative to the mean diagonal
     aa_safeguard: float = 1.0    # the point is kept when the next fixed-point residual <= this x the last one
