@@ -1591,7 +1591,7 @@ __global__ void __launch_bounds__(256) k_rho_rescale(OmcWS w) {
     w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
   }
   fr2 = block_sum(fr2, red);
-  if (tid == 0) { w.fro2[b] = fr2; w.bfac[b] = 1.0; if (w.accel) w.aa_valid[b] = 0; }   // the map changed: restart the history
+  if (tid == 0) { w.fro2[b] = fr2; w.bfac[b] = 1.0; if (w.accel && w.aa_valid[b] != 2) w.aa_valid[b] = 0; }   // the map changed: restart the history
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1613,6 +1613,7 @@ __global__ void __launch_bounds__(512) k_aa(OmcWS w) {
   if (w.done[b]) return;
   const int it = w.iters[b];
   if (it < w.aa_start - 1) return;
+  if (w.aa_valid[b] == 2) return;     // switched off for this node: its extrapolated points keep being rejected
   const int n = w.n, k = w.k, rm = w.rmax, dim = w.aa_dim, M1 = w.aa_mem + 1;
   AaSeg seg[8] = {{w.Y + (size_t)b * n * n, n * n}, {w.Yp + (size_t)b * n * n, n * n}, {w.D1 + (size_t)b * n * n, n * n},
                   {w.D3 + (size_t)b * n * n, n * n}, {w.Vt + (size_t)b * rm * k, rm * k}, {w.D3V + (size_t)b * rm * k, rm * k},
@@ -1666,7 +1667,11 @@ __global__ void __launch_bounds__(512) k_aa(OmcWS w) {
       o += seg[sgi].len;
     }
     rebuild_cone_input();
-    if (tid == 0) { w.aa_hist[b] = 0; w.aa_head[b] = 0; w.aa_pending[b] = 0; w.aa_nrej[b] += 1; }
+    if (tid == 0) {
+      w.aa_hist[b] = 0; w.aa_head[b] = 0; w.aa_pending[b] = 0; w.aa_nrej[b] += 1;
+      // a node that rejects its points (non-smooth map: active sets keep changing) pays for the history without using it: stop there
+      if (w.aa_nrej[b] >= 4 && w.aa_nrej[b] > w.aa_nacc[b]) w.aa_valid[b] = 2;
+    }
     return;
   }
   if (pending && tid == 0) w.aa_nacc[b] += 1;

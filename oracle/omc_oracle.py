@@ -671,7 +671,7 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
         for a in alpha:
             al.append(z[o:o + a.size].reshape(a.shape).copy()); o += a.size
         return outm, al
-    aa_valid = False; aa_F = []; aa_G = []; aa_zin = None; aa_pending = None; n_aa = n_aa_rej = 0
+    aa_valid = False; aa_F = []; aa_G = []; aa_zin = None; aa_pending = None; n_aa = n_aa_rej = n_aa_acc = 0; aa_off = False
     for it in range(1, p.max_iters + 1):
         rho_f = rho * p.rho_f_ratio
         alpha, svals, LL = _prox_columns(inst, 2.0 * Y - Yp, alpha, svals, rho_f)
@@ -739,7 +739,7 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
                 n_bumps += 1; last_bump = it
                 aa_valid = False                                       # the map changed: restart the history
         # ---- Anderson acceleration (mirrors k_aa: runs after the certificate, on the state the next iteration reads) ----
-        if p.accel and it >= p.aa_start - 1:
+        if p.accel and it >= p.aa_start - 1 and not aa_off:
             if not aa_valid:
                 aa_zin = aa_pack(); aa_F = []; aa_G = []; aa_pending = None; aa_valid = True
                 continue
@@ -747,7 +747,11 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
             if aa_pending is not None and not (fn <= p.aa_safeguard * aa_pending[0]):
                 (Y, Yp, D1, D3, Vt, D3V, D3T), alpha = aa_unpack(aa_pending[1])          # reject: back to the last plain image
                 aa_zin = aa_pending[1].copy(); aa_F = []; aa_G = []; aa_pending = None; n_aa_rej += 1
+                if n_aa_rej >= 4 and n_aa_rej > n_aa_acc:           # this node keeps rejecting its points: stop paying for the history
+                    aa_off = True
                 continue
+            if aa_pending is not None:
+                n_aa_acc += 1
             aa_pending = None
             aa_F.append(f); aa_G.append(gz)
             if len(aa_F) > p.aa_mem + 1:
