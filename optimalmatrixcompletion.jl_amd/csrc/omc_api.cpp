@@ -67,7 +67,7 @@ struct omc_instance {
   // batch workspace
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
-  DevBuf baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
+  DevBuf bobjcol, baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
   DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow;
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
   OmcWS ws{};
@@ -196,7 +196,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
-                   &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
+                   &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -434,6 +434,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.D3T = sm + 4 * vk; w.W3T = sm + 4 * vk + tk; w.Q3T = sm + 4 * vk + 2 * tk;
   }
   w.alpha = h->balpha.as<double>(); w.alphaX = h->balphaX.as<double>(); w.sval = h->bsval.as<double>();
+  ENS(h->bobjcol, sB * m * 2 * 8);
+  w.objcol = h->bobjcol.as<double>(); w.c0col = w.objcol + sB * m;
   w.Mchk = h->bMchk.as<double>(); w.chk_scratch = h->bchk.as<double>(); w.stamps = h->bchk.as<double>() + sB * n * k; w.G = h->bG.as<double>(); w.lam = h->blam.as<double>();
   double* sc = h->bscal.as<double>();
   w.obj = sc; w.objout = sc + sB; w.lb = sc + 2 * sB; w.c0 = sc + 3 * sB; w.evsum = sc + 4 * sB; w.cpen = sc + 5 * sB;

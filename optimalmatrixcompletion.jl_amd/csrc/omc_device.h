@@ -60,6 +60,7 @@ struct OmcWS {
   double* dS;             // rmax*rmax
   double *alpha, *alphaX; // nnz
   double* sval;           // m
+  double *objcol, *c0col; // m: per-column terms of the exact objective / Fenchel constant (k_colprox mode 1 -> k_check_build)
   double* Mchk;           // n*n
   double *Mbuf, *Vrow;    // np16*np16: next cone input Y - D1 (zero padded) ; eigenvectors of the last projection, row-major
   double* fro2;           // B: ||Mbuf||_F^2

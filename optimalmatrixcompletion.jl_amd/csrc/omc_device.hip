@@ -251,7 +251,7 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
     WAVE_SYNC();
     bool ok = wave_cholesky(Lm, c, lane);
     if (!ok) {  // Y not PSD enough on this block: report +inf objective contribution
-      if (lane == 0) atomicAdd(&w.obj[b], 1e300);
+      if (lane == 0) { w.objcol[(size_t)b * w.m + j] = 1e300; w.c0col[(size_t)b * w.m + j] = 0.0; }
       return;
     }
     double yr = 0.0, zr = 0.0;
@@ -260,10 +260,7 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
     if (regpath) { aa = a_reg * yr; al2 = yr * yr; if (lane < c) alpha[lane] = yr; }
     else for (int p = lane; p < c; p += WAVE) { aa += va[p] * vy[p]; al2 += vy[p] * vy[p]; alpha[p] = vy[p]; }
     aa = wave_sum(aa); al2 = wave_sum(al2);
-    if (lane == 0) {
-      atomicAdd(&w.obj[b], 0.5 * aa);
-      atomicAdd(&w.c0[b], aa - 0.5 * al2);
-    }
+    if (lane == 0) { w.objcol[(size_t)b * w.m + j] = 0.5 * aa; w.c0col[(size_t)b * w.m + j] = aa - 0.5 * al2; }   // summed in a fixed order by k_check_build
   }
 }
 
@@ -403,16 +400,13 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
     WSTAMP(27);
   } else {
     if (!wave_ldl(Lm, pinv, c, lane)) {  // Y not PSD enough on this block: report +inf objective contribution
-      if (lane == 0) atomicAdd(&w.obj[b], 1e300);
+      if (lane == 0) { w.objcol[(size_t)b * w.m + j] = 1e300; w.c0col[(size_t)b * w.m + j] = 0.0; }
       return;
     }
     const double yr = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
     if (lane < c) alpha[lane] = yr;
     const double aa = wave_sum(a_reg * yr), al2 = wave_sum(yr * yr);
-    if (lane == 0) {
-      atomicAdd(&w.obj[b], 0.5 * aa);
-      atomicAdd(&w.c0[b], aa - 0.5 * al2);
-    }
+    if (lane == 0) { w.objcol[(size_t)b * w.m + j] = 0.5 * aa; w.c0col[(size_t)b * w.m + j] = aa - 0.5 * al2; }   // summed in a fixed order by k_check_build
   }
 }
 
@@ -424,7 +418,7 @@ __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   if (bl >= w.nB) return;
   if (w.done[b]) return;
   const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
-  if (c == 0) return;
+  if (c == 0) { if (mode == 1 && lane == 0) { w.objcol[(size_t)b * w.m + j] = 0.0; w.c0col[(size_t)b * w.m + j] = 0.0; } return; }
   DIAG_T0();
   // two inlined copies so that the LDS copy compiles to ds_read/ds_write (not flat) instructions
   if (c <= w.cp_lds_c) colprox_reg(w, mode, b, j, off, c, lane, smem + (size_t)wave_in_blk * w.cp_lds_doubles);   // cp_lds_c <= 64
@@ -1482,6 +1476,12 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
   const double* Q = w.Qb + (size_t)nb * n * rm;
   const double rho = w.rho_b[b], g = w.gamma;
   double* cU = w.chk_scratch + (size_t)b * n * k;
+  {   // exact objective and Fenchel constant: per-column terms of k_colprox (mode 1) added in a fixed order (no atomics: run-to-run identical)
+    double so = 0.0, sc = 0.0;
+    for (int j = tid; j < m; j += T) { so += w.objcol[(size_t)b * m + j]; sc += w.c0col[(size_t)b * m + j]; }
+    so = block_sum(so, red); sc = block_sum(sc, red);
+    if (tid == 0) { w.obj[b] = so; w.c0[b] = sc; }
+  }
   for (int e = tid; e < n * n; e += T) {
     int i = e % n, j = e / n;
     double v = -rho * E3[e];
