@@ -304,6 +304,8 @@ def nnqp(G, c, tol=1e-13):
         P[t] = True
         for _ in range(10 * R + 10):
             idx = np.flatnonzero(P)
+            if len(idx) == 0:                    # every passive index was dropped again (degenerate rows): back to the outer test
+                break
             s = np.zeros(R)
             s[idx] = np.linalg.lstsq(G[np.ix_(idx, idx)], c[idx], rcond=None)[0]
             if s[idx].min() > 0:
