@@ -524,11 +524,14 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       // G lives in LDS when it fits, else in the per-node global scratch (L2 resident) with 16 lanes per pair.
       const int Np2 = (n + 1) & ~1;
       int lpp = 16; while (lpp > 4 && lpp * (Np2 / 2) > 512) lpp >>= 1;
-      int rpl = (((n + lpp - 1) / lpp) + 1) & ~1, Nrp = rpl * lpp, ldw = Nrp + 2;
+      int rpl = (((n + lpp - 1) / lpp) + 1) & ~1, Nrp = rpl * lpp;
+      int ldw = Nrp + ((16 - (Nrp & 31)) & 31);                 // 16 (mod 32): neighbouring columns start 32 LDS banks apart
+      if (((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64 > OMC_MAX_DYN_LDS) ldw = Nrp + 2;   // does not fit: plain padding
       h->ws_lds = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
       h->ws_use_lds = h->ws_lds <= OMC_MAX_DYN_LDS;
+      w.ws_ld = ldw;
       if (!h->ws_use_lds) {
-        lpp = 16; rpl = (((n + 15) / 16) + 1) & ~1; Nrp = rpl * 16; ldw = Nrp + 2;
+        lpp = 16; rpl = (((n + 15) / 16) + 1) & ~1; Nrp = rpl * 16; ldw = Nrp + 2; w.ws_ld = ldw;
         const size_t need = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
         if (need / 8 + 8 > w.cone_scratch_stride) {
           w.cone_scratch_stride = need / 8 + 8;

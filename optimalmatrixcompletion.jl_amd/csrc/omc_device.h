@@ -67,6 +67,7 @@ struct OmcWS {
   int* vvalid;            // B: Vrow holds eigenvectors
   // the same triple for the certificate matrix Mchk (k_cone_ws with ws_mode = 1 returns the k smallest eigenvalues only)
   double *MbufC, *VrowC, *fro2c; int* vvalidC; int ws_mode;
+  int ws_ld;              // leading dimension of G in k_cone_ws (chosen on the host: 16 mod 32 when it fits)
   // rows
   int* R;                 // B
   int *rkind, *rcut, *rbi, *rbj;  // B*Rmax

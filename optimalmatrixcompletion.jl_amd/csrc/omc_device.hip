@@ -834,7 +834,11 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   const int n = w.n, N = n, NP = w.np16;
   const int Np = (N + 1) & ~1;
   // lane lg of a pair group owns the CONTIGUOUS rows [lg*rpl, (lg+1)*rpl): 16-byte LDS reads, rpl even, ld even
-  const int rpl = (((N + LPP - 1) / LPP) + 1) & ~1, Nrp = rpl * LPP, ld = Nrp + 2;
+  const int rpl = (((N + LPP - 1) / LPP) + 1) & ~1, Nrp = rpl * LPP;
+  // leading dimension = 16 (mod 32) doubles and rows interleaved over the lanes of a pair group (lane lg owns the 16-byte chunks
+  // lg, lg + LPP, ...): a group then reads 128 contiguous bytes = 32 banks, and the groups of neighbouring pairs (columns p, p + 1)
+  // start 32 banks apart -- the contiguous-rows layout with ld = Nrp + 2 lost 36 % of the LDS cycles to bank conflicts (PMC)
+  const int ld = w.ws_ld;
   auto Gm = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.cone_scratch + (size_t)b * w.cone_scratch_stride; }();
   auto ev = Gm + (size_t)Np * ld;
   auto wgt = ev + Np;
@@ -919,15 +923,15 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
           int p, q;
           rr_pair(step, pr, Np, p, q);
           typedef double double2v __attribute__((ext_vector_type(2)));
-          auto gp = (double2v*)(Gm + (size_t)p * ld + lg * rpl);
-          auto gq = (double2v*)(Gm + (size_t)q * ld + lg * rpl);
+          auto gp = (double2v*)(Gm + (size_t)p * ld) + lg;
+          auto gq = (double2v*)(Gm + (size_t)q * ld) + lg;
           const int rpl2 = rpl >> 1;
           constexpr int R2 = RPL2 ? RPL2 : WS_JROWS / 2;
           double2v cp_[R2], cq_[R2];
           double gm0 = 0.0, gm1 = 0.0;
 #pragma unroll
           for (int i = 0; i < R2; ++i) {
-            if (RPL2 || i < rpl2) { cp_[i] = gp[i]; cq_[i] = gq[i]; gm0 += cp_[i].x * cq_[i].x; gm1 += cp_[i].y * cq_[i].y; }
+            if (RPL2 || i < rpl2) { cp_[i] = gp[i * LPP]; cq_[i] = gq[i * LPP]; gm0 += cp_[i].x * cq_[i].x; gm1 += cp_[i].y * cq_[i].y; }
           }
           double gm = group_sum_dpp<LPP>(gm0 + gm1);
           const double a = ev[p], bb = ev[q];
@@ -946,7 +950,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
                 double2v np_, nq_;
                 np_.x = cs * cp_[i].x - sn * cq_[i].x; np_.y = cs * cp_[i].y - sn * cq_[i].y;
                 nq_.x = sn * cp_[i].x + cs * cq_[i].x; nq_.y = sn * cp_[i].y + cs * cq_[i].y;
-                gp[i] = np_; gq[i] = nq_;
+                gp[i * LPP] = np_; gq[i * LPP] = nq_;
               }
             }
             if (lg == 0) { ev[p] = a - tt * gm; ev[q] = bb + tt * gm; }
