@@ -421,6 +421,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   if (!getenv("OMC_COLD_CHECK")) {   // warm-started eigenvalues for the certificate matrix
     ENS(h->bMbufC, sB * w.np16 * w.np16 * 8); ENS(h->bVrowC, sB * w.np16 * w.np16 * 8); ENS(h->bchkS, sB * 8); ENS(h->bchkI, sB * sizeof(int));
     HIPCHK(hipMemsetAsync(h->bMbufC.p, 0, sB * w.np16 * w.np16 * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->bVrowC.p, 0, sB * w.np16 * w.np16 * 8, h->stream));   // its zero padding feeds the branch-free K loop of the MFMA GEMM: 0 x garbage could be NaN
     HIPCHK(hipMemsetAsync(h->bchkI.p, 0, sB * sizeof(int), h->stream));
     w.MbufC = h->bMbufC.as<double>(); w.VrowC = h->bVrowC.as<double>(); w.fro2c = h->bchkS.as<double>(); w.vvalidC = h->bchkI.as<int>();
   }
