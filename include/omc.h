@@ -187,9 +187,14 @@ int omc_shor_last_stats(omc_instance* h, double* ms, int64_t* candidates);
 #define OMC_KERNEL_SETUP 4
 #define OMC_KERNEL_SMALL 5
 #define OMC_KERNEL_ACCEL 6
-#define OMC_KERNEL_NCLASS 7
+#define OMC_KERNEL_CONESUB 7   /* k_cone_sub: the cone block by tracking the dominant 16-dimensional subspace */
+#define OMC_KERNEL_NCLASS 8
 /* info[8]: solve seconds, total Jacobi sweeps of k_cone, rho, r_max, LDS flags (cone, global, small), R_max */
 int omc_last_solver_info(omc_instance* h, double* info);
+/* out[8] of the last omc_relax_solve: calls of k_cone_sub, its power steps, calls that fell back to the full eigendecomposition,
+ * seedings of the tracked subspace by the full kernel, fall-backs by cause (more than 12 positive Ritz values, step cap, Cholesky
+ * breakdown), Rayleigh-Ritz passes */
+int omc_last_subspace_stats(omc_instance* h, int64_t* out);
 /* diagnostic builds (-DOMC_STAMPS) only: accumulated s_memtime ticks per kernel phase of node 0; zeros otherwise */
 int omc_debug_stamps(omc_instance* h, double* out32);
 /* diagnostic builds only: per-slot counters, out[c * slots + b]: c = 0 colprox wave cycles, 1 factorizations, 2 cone cycles,

@@ -14,7 +14,7 @@ EXPORTS = [
     "omc_relax_params_default", "omc_last_error", "omc_version", "omc_device_count", "omc_instance_create",
     "omc_instance_create_bits", "omc_instance_destroy", "omc_relax_batch", "omc_relax_stage", "omc_relax_solve",
     "omc_relax_fetch", "omc_altmin_batch", "omc_evaluate_objective", "omc_separation_batch", "omc_round_Y_batch",
-    "omc_last_kernel_stats", "omc_last_solver_info", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
+    "omc_last_kernel_stats", "omc_last_solver_info", "omc_last_subspace_stats", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
     "omc_shor_count", "omc_shor_indexes", "omc_violated_shor_minors", "omc_shor_last_stats",
 ]
 
@@ -64,6 +64,7 @@ def load():
     lib.omc_round_Y_batch.argtypes = [vp, C.c_int, vp, vp]
     lib.omc_last_kernel_stats.argtypes = [vp, vp, vp, vp]
     lib.omc_last_solver_info.argtypes = [vp, vp]
+    lib.omc_last_subspace_stats.argtypes = [vp, vp]
     lib.omc_set_node_rho_scales.argtypes = [vp, C.c_int, vp]
     lib.omc_debug_stamps.argtypes = [vp, vp]
     lib.omc_debug_residuals.argtypes = [vp, vp, vp]

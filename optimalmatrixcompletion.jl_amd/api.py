@@ -23,7 +23,7 @@ CUT_TYPES = {"linear": 0, "linear2": 1, "linear3": 2}
 DIR_CODES = {"left": 0, "middle": 1, "right": 2, "inner_left": 3, "inner_right": 4}
 BREAKPOINTS = {"smallest_1_eigvec": 1, "smallest_2_eigvec": 2}
 STATUS_NAMES = {0: "OPTIMAL", 1: "SLOW_PROGRESS", 2: "TIME_LIMIT", 3: "INFEASIBLE"}
-KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small", "accel"]
+KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small", "accel", "cone_sub"]
 
 
 def default_params(**kw) -> RelaxParams:
@@ -141,6 +141,13 @@ class Engine:
         nc = len(KERNEL_CLASSES); la = np.zeros(nc, np.int64); ms = np.zeros(nc); un = np.zeros(nc, np.int64)
         _lib.check(self._lib.omc_last_kernel_stats(self._h, _lib.ptr(la), _lib.ptr(ms), _lib.ptr(un)))
         return {KERNEL_CLASSES[i]: dict(launches=int(la[i]), ms=float(ms[i]), units=int(un[i])) for i in range(nc)}
+
+    def subspace_stats(self):
+        """k_cone_sub accounting of the last solve: calls, power steps, fall-backs to the full eigendecomposition, seedings."""
+        out = np.zeros(8, np.int64)
+        _lib.check(self._lib.omc_last_subspace_stats(self._h, _lib.ptr(out)))
+        return dict(calls=int(out[0]), power_steps=int(out[1]), fallbacks=int(out[2]), seeds=int(out[3]), fail_positive=int(out[4]),
+                    fail_steps=int(out[5]), fail_cholesky=int(out[6]), ritz_passes=int(out[7]))
 
     def solver_info(self):
         info = np.zeros(8)

@@ -22,13 +22,26 @@ __device__ __forceinline__ double am_row_entry(const AltminWS& w, int b, int r, 
   return cf * w.cutx[((size_t)b * w.Lmax + w.rcut[(size_t)b * w.Rmax + r]) * w.n + i];
 }
 
+#define AM_MAX_DOUBLINGS 64      // bracket search of the ball multiplier (theta <= 2^64 max|g|: beyond that model_U is infeasible)
+#define AM_FEAS_TOL 1e-6         // largest row violation / excess of ||u||^2 - 1 accepted from a U-step (the oracle uses the same)
+__device__ __forceinline__ double block_max(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) red[wv] = v;
+  __syncthreads();
+  double s = red[0];
+  for (int i = 1; i < nw; ++i) s = fmax(s, red[i]);
+  return s;
+}
+
 __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
   extern __shared__ double sm[];
   __shared__ double red[32];
   __shared__ double s_Gp[NNQP_PMAX * (NNQP_PMAX + 1) / 2];
   __shared__ double s_sv[NNQP_PMAX], s_tmp[NNQP_PMAX];
   __shared__ int s_pl[NNQP_PMAX];
-  __shared__ int s_stop;
+  __shared__ int s_stop, s_ov;
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int n = w.n, m = w.m, R = w.R[b];
   double* u = sm;            // n
@@ -45,7 +58,7 @@ __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
   for (int t = tid; t < w.max_iters; t += T) objs[t] = __longlong_as_double(0x7ff8000000000000LL);  // NaN padding
   __syncthreads();
   double objective_current = 1e10;   // OMC.jl:2012
-  int counter = 0, converged = 0;
+  int counter = 0, converged = 0, failed = 0;
   while (counter < w.max_iters) {
     ++counter;
     // ---- V-step ------------------------------------------------------------------------------------------
@@ -87,7 +100,7 @@ __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
         cvec[r] = acc - w.rrhs[(size_t)b * w.Rmax + r];
       }
       __syncthreads();
-      if (R > 0 && tid < 64) wave_nnqp(G, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid);
+      if (R > 0 && tid < 64) { const int ov = wave_nnqp(G, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid); if (tid == 0) s_ov = ov; }
       __syncthreads();
       double nn = 0.0;
       for (int i = tid; i < n; i += T) {
@@ -98,16 +111,35 @@ __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
       }
       return block_sum(nn, red);
     };
+    if (tid == 0) s_ov = 0;
+    __syncthreads();
     if (solve(0.0) > 1.0) {                       // ball active (OMC.jl:2164-2171)
       double lo_t = 0.0, hi_t = 1.0;
       for (int i = 0; i < n; ++i) hi_t = fmax(hi_t, fabs(g[i]));
-      while (solve(hi_t) > 1.0) hi_t *= 2.0;
+      // an infeasible model_U (contradictory cut bounds, or rows that leave no point inside the unit ball) never enters the ball:
+      // the bracket search is capped and the feasibility test below reports the failure
+      for (int dbl = 0; dbl < AM_MAX_DOUBLINGS && solve(hi_t) > 1.0; ++dbl) hi_t *= 2.0;
       for (int it = 0; it < 200; ++it) {
         const double theta = 0.5 * (lo_t + hi_t);
         if (solve(theta) > 1.0) lo_t = theta; else hi_t = theta;
         if (hi_t - lo_t <= 1e-15 * fmax(1.0, hi_t)) break;
       }
       solve(hi_t);
+    }
+    // ---- did model_U have a solution?  (OMC.jl:2231, 2263-2265: a failed solve ends the loop with converged = false) ---------
+    {
+      double viol = 0.0, nn = 0.0;
+      for (int r = tid; r < R; r += T) {
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += am_row_entry(w, b, r, i) * u[i];
+        viol = fmax(viol, acc - w.rrhs[(size_t)b * w.Rmax + r]);
+      }
+      for (int i = tid; i < n; i += T) nn += u[i] * u[i];
+      nn = block_sum(nn, red);
+      viol = block_max(viol, red);
+      const bool bad = !(viol <= AM_FEAS_TOL) || !(nn <= 1.0 + AM_FEAS_TOL) || s_ov;
+      __syncthreads();
+      if (bad) { failed = 1; break; }
     }
     // ---- objective of model_U (OMC.jl:2232) ------------------------------------------------------------------
     double q = 0.0;
@@ -132,7 +164,7 @@ __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
   }
   for (int i = tid; i < n; i += T) w.U[(size_t)b * n + i] = u[i];
   for (int j = tid; j < m; j += T) w.V[(size_t)b * m + j] = v[j];
-  if (tid == 0) { w.converged[b] = converged; w.n_iters[b] = counter; }
+  if (tid == 0) { w.converged[b] = failed ? 0 : converged; w.n_iters[b] = counter; }
 }
 
 
@@ -185,7 +217,7 @@ __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
   __shared__ int s_pl[NNQP_PMAX];
   __shared__ double s_th[AK_QMAX], s_th2[AK_QMAX], s_q[AK_QMAX], s_qt[AK_QMAX], s_W[AK_QMAX * AK_KMAX], s_rad[AK_QMAX];
   __shared__ double s_J[AK_QMAX * AK_QMAX], s_P[AK_QMAX * AK_QMAX], s_L[AK_QMAX * AK_QMAX], s_step[AK_QMAX];
-  __shared__ int s_act[AK_QMAX], s_nact, s_flag, s_stop;
+  __shared__ int s_act[AK_QMAX], s_nact, s_flag, s_stop, s_ov;
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   const int n = w.n, m = w.m, k = w.k, kk = k * k, mq = k * k, R = w.R[b];
   double* u = sm;                 // n*k, row i at u + i*k  (accepted iterate)
@@ -259,7 +291,7 @@ __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
       cvec[r] = acc - w.rrhs[(size_t)b * w.Rmax + r];
     }
     __syncthreads();
-    if (R > 0 && tid < 64) wave_nnqp(G, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid);
+    if (R > 0 && tid < 64) { const int ov = wave_nnqp(G, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid); if (tid == 0 && ov) s_ov = 1; }
     __syncthreads();
     double pv = 0.0;
     double qa[AK_QMAX];
@@ -310,7 +342,7 @@ __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
   auto dotq = [&](const double* th, const double* q) { double r_ = 0.0; for (int c = 0; c < mq; ++c) r_ += th[c] * q[c]; return r_; };
 
   double objective_current = 1e10;   // OMC.jl:2012
-  int counter = 0, converged = 0;
+  int counter = 0, converged = 0, failed = 0;
   while (counter < w.max_iters) {
     ++counter;
     // ---- V-step (model_V, OMC.jl:2192-2209): (sum_{i in O_j} u_i u_i' + U'U / gamma) v_j = sum_{i in O_j} A_ij u_i ---------
@@ -389,6 +421,8 @@ __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
     if (tid == 0) for (int c = 0; c < mq; ++c) s_th[c] = 0.0;
     __syncthreads();
     // ---- U-step: projected Newton on the dual ------------------------------------------------------------------------------
+    if (tid == 0) s_ov = 0;
+    __syncthreads();
     double pv = evaluate(s_th, s_q);
     for (int e = tid; e < n * k; e += T) u[e] = ut[e];
     __syncthreads();
@@ -453,6 +487,22 @@ __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
       }
       if (!accepted) break;
     }
+    // ---- did model_U have a solution?  (OMC.jl:2231, 2263-2265: a failed solve ends the loop with converged = false) ---------
+    {
+      double viol = 0.0;
+      for (int r = tid; r < R; r += T) {
+        const int j = w.rbj[(size_t)b * w.Rmax + r];
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += ak_row_x(w, b, r, i) * u[i * k + j];
+        viol = fmax(viol, acc - w.rrhs[(size_t)b * w.Rmax + r]);
+      }
+      for (int c = 0; c < mq; ++c) viol = fmax(viol, s_q[c]);
+      viol = block_max(viol, red);
+      // s_ov is sticky over the evaluations of this U-step: a rejected trial may have set it, so it is only trusted together with a violation
+      const bool bad = !(viol <= AM_FEAS_TOL) || (s_ov && viol > 1e-9);
+      __syncthreads();
+      if (bad) { failed = 1; break; }
+    }
     // ---- objective of model_U (OMC.jl:2232) and the convergence rules (2234-2245, quirk Q3) ---------------------------------
     const double objective_new = pv + 0.5 * w.sumA2;
     if (tid == 0) {
@@ -474,7 +524,7 @@ __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
   }
   for (int e = tid; e < n * k; e += T) { const int i = e % n, a = e / n; w.U[(size_t)b * n * k + e] = u[i * k + a]; }
   for (int e = tid; e < k * m; e += T) w.V[(size_t)b * k * m + e] = v[e];      // k x m column-major = v[j*k + a]
-  if (tid == 0) { w.converged[b] = converged; w.n_iters[b] = counter; }
+  if (tid == 0) { w.converged[b] = failed ? 0 : converged; w.n_iters[b] = counter; }
 }
 
 extern "C" void omc_launch_altmin_k(const void* ws, size_t lds_bytes, hipStream_t s) {
@@ -489,5 +539,5 @@ extern "C" void omc_launch_altmin(const void* ws, size_t lds_bytes, hipStream_t 
 extern "C" int omc_altmin_set_lds(void) {
   // k_altmin_k holds ~20 KB of static LDS (Newton scratch, NNQP): its dynamic budget is 128 KB
   if (hipFuncSetAttribute((const void*)k_altmin_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) (void)hipGetLastError();
-  return (int)hipFuncSetAttribute((const void*)k_altmin, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  return (int)hipFuncSetAttribute((const void*)k_altmin, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS - 8 * 1024);   // ~18 KB static (NNQP scratch)
 }

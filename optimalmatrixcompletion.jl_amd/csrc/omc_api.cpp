@@ -68,7 +68,8 @@ struct omc_instance {
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
   DevBuf bobjcol, baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
-  DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow;
+  DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow, bXs, bsubS, bsubI;
+  long long sub_tot[8] = {0};
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
   OmcWS ws{};
   omc_relax_params params{};
@@ -171,7 +172,7 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   HIPCHK(hipStreamSynchronize(h->stream));
   int lrc = omc_set_max_lds();
   if (lrc) { delete h; return fail(lrc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); }
-  (void)omc_altmin_set_lds();
+  { int arc = omc_altmin_set_lds(); if (arc) { delete h; return fail(5000 + arc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the altmin kernel"); } }
   omc_relax_params_default(&h->params);
   *out = h;
   return 0;
@@ -193,7 +194,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
-                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow,
+                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
@@ -411,13 +412,27 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   ENS(h->balpha, sB * h->nnz * 8); ENS(h->balphaX, sB * h->nnz * 8); ENS(h->bsval, sB * m * 8);
   ENS(h->bMchk, sB * n * n * 8); ENS(h->bchk, sB * n * k * 8 + (32 + 8 * sB) * 8);
   ENS(h->bG, sB * Rmax * Rmax * 8); ENS(h->blam, sB * Rmax * 8);
-  ENS(h->bscal, sB * 16 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 8 * sizeof(int));
+  ENS(h->bscal, sB * 16 * 8); ENS(h->bbx, sB * n * 8); ENS(h->bint, sB * 10 * sizeof(int));
   w.np16 = (n + 15) & ~15;
   ENS(h->bMbuf, sB * w.np16 * w.np16 * 8); ENS(h->bVrow, sB * w.np16 * w.np16 * 8);
   ENS(h->blamD, sB * m * n * 8);
   HIPCHK(hipMemsetAsync(h->blamD.p, 0, sB * m * n * 8, h->stream));
   w.lamD = h->blamD.as<double>();
   w.Mbuf = h->bMbuf.as<double>(); w.Vrow = h->bVrow.as<double>();
+  {   // tracked subspace of the cone block (k_cone_sub)
+    ENS(h->bXs, sB * w.np16 * 16 * 8); ENS(h->bsubS, sB * 17 * 8); ENS(h->bsubI, sB * 12 * sizeof(int));
+    HIPCHK(hipMemsetAsync(h->bXs.p, 0, sB * w.np16 * 16 * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->bsubS.p, 0, sB * 17 * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->bsubI.p, 0, sB * 12 * sizeof(int), h->stream));
+    w.Xs = h->bXs.as<double>(); w.sub_theta = h->bsubS.as<double>(); w.trM = h->bsubS.as<double>() + sB * 16;
+    w.sub_on = h->bsubI.as<int>(); w.cone_done = h->bsubI.as<int>() + sB; w.sub_stat = h->bsubI.as<int>() + 2 * sB; w.sub_wait = h->bsubI.as<int>() + 10 * sB; w.sub_nfail = h->bsubI.as<int>() + 11 * sB;
+    w.sub_qmax = getenv("OMC_SUB_QMAX") ? atoi(getenv("OMC_SUB_QMAX")) : 24;
+    w.sub_chunk = getenv("OMC_SUB_CHUNK") ? atoi(getenv("OMC_SUB_CHUNK")) : 4;
+    w.sub_tol = getenv("OMC_SUB_TOL") ? atof(getenv("OMC_SUB_TOL")) : 1e-10;
+    w.sub_adapt = getenv("OMC_SUB_ADAPT") ? atof(getenv("OMC_SUB_ADAPT")) : 1e-3;
+    w.sub_debug = getenv("OMC_SUB_DEBUG") ? atoi(getenv("OMC_SUB_DEBUG")) : 0;
+    w.sub_enable = 0;     // decided below, once the cone kernel variant is known
+  }
   if (!getenv("OMC_COLD_CHECK")) {   // warm-started eigenvalues for the certificate matrix
     ENS(h->bMbufC, sB * w.np16 * w.np16 * 8); ENS(h->bVrowC, sB * w.np16 * w.np16 * 8); ENS(h->bchkS, sB * 8); ENS(h->bchkI, sB * sizeof(int));
     HIPCHK(hipMemsetAsync(h->bMbufC.p, 0, sB * w.np16 * w.np16 * 8, h->stream));
@@ -453,7 +468,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     HIPCHK(hipMemsetAsync(ai, 0, sB * 6 * sizeof(int), h->stream));
   }
   int* ip = h->bint.as<int>();
-  w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB; w.vvalid = ip + 5 * sB; w.nbump = ip + 6 * sB; w.lastbump = ip + 7 * sB;
+  w.done = ip; w.status = ip + sB; w.iters = ip + 2 * sB; w.sweeps = ip + 3 * sB; w.stall = ip + 4 * sB; w.vvalid = ip + 5 * sB; w.nbump = ip + 6 * sB; w.lastbump = ip + 7 * sB; w.rowov = ip + 8 * sB;
   {
     ENS(h->bslotint, sB * 3 * sizeof(int));
     int* si = h->bslotint.as<int>();
@@ -541,9 +556,11 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
         }
       }
       h->ws_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;   // WS_JROWS
+      // subspace tracking needs the warm-started kernel as its seed / fall-back and at least 3 x 16 rows
+      w.sub_enable = (h->ws_lpp && n >= 48 && w.np16 <= 192 && omc_cone_sub_lds(w.np16) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE")) ? 1 : 0;
     }
     h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8 + (size_t)h->nnz * 4 + 16;   // n*m >= n*n: the region also stages Lambda
-    h->glob_use_lds = h->glob_lds + 12 * 1024 <= OMC_MAX_DYN_LDS;
+    h->glob_use_lds = h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS;   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
     if (!h->glob_use_lds) {
       w.glob_scratch_stride = h->glob_lds / 8 + 8;
       ENS(h->bglob, sB * w.glob_scratch_stride * 8);
@@ -645,6 +662,7 @@ int omc_relax_solve(omc_instance* h) {
         HIPCHK(hipStreamWaitEvent(sb, h->gev[g][0], 0)); HIPCHK(hipStreamWaitEvent(sc, h->gev[g][0], 0));
       }
       TIMED_ON(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
+      if (w.sub_enable) TIMED_ON(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
       if (h->ws_lpp) TIMED_ON(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
       else TIMED_ON(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone(&wg, CONE_CLIP01, h->cone_use_lds, h->cone_lds, sm));
       TIMED_ON(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
@@ -736,6 +754,12 @@ int omc_relax_solve(omc_instance* h) {
     HIPCHK(hipMemcpyAsync(sw.data(), w.sweeps, sizeof(int) * S, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int v : sw) h->total_sweeps += v;
+    std::vector<int> ss(8 * (size_t)S);
+    HIPCHK(hipMemcpyAsync(ss.data(), w.sub_stat, sizeof(int) * ss.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int q = 0; q < 8; ++q) h->sub_tot[q] = 0;
+    for (int b = 0; b < S; ++b) for (int q = 0; q < 8; ++q) h->sub_tot[q] += ss[8 * b + q];
+    HIPCHK(hipMemsetAsync(w.sub_stat, 0, sizeof(int) * ss.size(), s));
   }
   HIPCHK(hipGetLastError());
   finish_events(h);
@@ -922,7 +946,7 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   w.converged = h->aint.as<int>(); w.n_iters = h->aint.as<int>() + B; w.G = h->aG.as<double>();
   const size_t lds = (k == 1) ? ((size_t)4 * n + m + 2 * Rmax + 8) * 8
                               : ((size_t)4 * n * k + (size_t)2 * n * k * k + (size_t)k * m + 2 * Rmax + 8) * 8;
-  if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS : (size_t)128 * 1024)) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: n, m too large for the LDS-resident kernel of this round");
+  if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS - 8 * 1024 : (size_t)128 * 1024)) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: n, m too large for the LDS-resident kernel of this round");
   if (k == 1) omc_launch_altmin(&w, lds, s); else omc_launch_altmin_k(&w, lds, s);
   HIPCHK(hipMemcpyAsync(U, w.U, 8 * sB * n * k, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(V, w.V, 8 * sB * m * k, hipMemcpyDeviceToHost, s));
@@ -1174,6 +1198,12 @@ int omc_last_solver_info(omc_instance* h, double* info) {
   if (!h || !info) return fail(OMC_ERR_ARGUMENT, "NULL argument");
   info[0] = h->last_solve_seconds; info[1] = (double)h->total_sweeps; info[2] = h->ws.rho; info[3] = (double)h->ws.rmax;
   info[4] = (double)h->cone_use_lds; info[5] = (double)h->glob_use_lds; info[6] = (double)h->small_use_lds; info[7] = (double)h->ws.Rmax;
+  return 0;
+}
+
+int omc_last_subspace_stats(omc_instance* h, int64_t* out) {
+  if (!h || !out) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  for (int q = 0; q < 8; ++q) out[q] = h->sub_tot[q];
   return 0;
 }
 

@@ -21,7 +21,7 @@
 #define OMC_ST_TIME 2
 #define OMC_ST_INFEASIBLE 3
 
-#define NNQP_PMAX 48
+#define NNQP_PMAX 64
 #define OMC_MAX_DYN_LDS (144 * 1024)
 
 struct OmcWS {
@@ -68,6 +68,15 @@ struct OmcWS {
   // the same triple for the certificate matrix Mchk (k_cone_ws with ws_mode = 1 returns the k smallest eigenvalues only)
   double *MbufC, *VrowC, *fro2c; int* vvalidC; int ws_mode;
   int ws_ld;              // leading dimension of G in k_cone_ws (chosen on the host: 16 mod 32 when it fits)
+  // tracked top-16 subspace of the cone input (k_cone_sub): once Y has settled, clip(M, 0, 1) = sum over the FEW positive eigenpairs
+  // (config 2: 2 of 100), so only the dominant invariant subspace is followed from one ADMM iteration to the next
+  int sub_enable, sub_qmax, sub_chunk, sub_debug; double sub_tol, sub_adapt;
+  double* Xs;             // B * np16 * 16: orthonormal Ritz basis (column-major, ld = np16, zero padded rows)
+  double* sub_theta;      // B * 16: Ritz values of the last accepted call
+  double* trM;            // B: trace of Mbuf (with fro2 it bounds the untracked part of the spectrum)
+  int *sub_wait, *sub_nfail; // B: iterations left before the subspace is tried again after a failure ; failures so far (back-off)
+  int *sub_on, *cone_done;   // B: slot follows the subspace ; this iteration's W1 has been written by k_cone_sub
+  int* sub_stat;          // B * 8: calls, power steps, failures (fall back to the full decomposition), seeds, failures by cause (too many positive Ritz values, step cap, Cholesky), Rayleigh-Ritz passes
   // rows
   int* R;                 // B
   int *rkind, *rcut, *rbi, *rbj;  // B*Rmax
@@ -80,6 +89,7 @@ struct OmcWS {
   double *obj, *objout, *objprev, *lbprev, *lb, *c0, *evsum, *cpen, *cst, *rp, *rd, *lmin;  // B (lmin 2B)
   double* bx;             // B*n
   int *done, *status, *iters, *sweeps, *stall;
+  int* rowov;             // B: 1 = the last row projection overflowed its passive set (NNQP_PMAX): the iterate may violate rows
   // scratch
   double* cp_scratch;  size_t cp_scratch_stride;   // per wave (B*m waves) when a column is too large for LDS
   int cp_lds_c; int cp_lds_doubles; int cp_keepB;   // cp_keepB = 0: dense columns, B is gathered again instead of kept in LDS
@@ -107,6 +117,8 @@ void omc_launch_cone(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hi
 void omc_launch_global(const OmcWS* w, int use_lds, size_t lds_bytes, hipStream_t s);
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s);
 void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, hipStream_t s);
+void omc_launch_cone_sub(const OmcWS* w, hipStream_t s);
+size_t omc_cone_sub_lds(int np16);
 void omc_launch_check_zero(const OmcWS* w, hipStream_t s);
 void omc_launch_check_build(const OmcWS* w, hipStream_t s);
 void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);

@@ -79,7 +79,9 @@ __global__ void k_setup(OmcWS w) {
       w.Mbuf[(size_t)b * NP * NP + e] = (i == j && i < n) ? d0 : 0.0;
       w.Vrow[(size_t)b * NP * NP + e] = 0.0;
     }
-    if (tid == 0) { w.fro2[b] = d0 * d0 * n; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0; }
+    if (tid == 0) {
+      w.fro2[b] = d0 * d0 * n; w.trM[b] = d0 * n; w.sub_on[b] = 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
+    }
   }
   for (int e = tid; e < n * k; e += T) w.U[(size_t)b * n * k + e] = 0.0;
   for (int e = tid; e < rm * k; e += T) {
@@ -97,7 +99,7 @@ __global__ void k_setup(OmcWS w) {
   if (tid == 0) {
     w.init[b] = 0; w.rho_b[b] = w.rho_node[nb];
     if (w.accel) { w.aa_valid[b] = 0; w.aa_hist[b] = 0; w.aa_head[b] = 0; w.aa_pending[b] = 0; w.aa_nacc[b] = 0; w.aa_nrej[b] = 0; }
-    w.done[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0; w.nbump[b] = 0; w.lastbump[b] = 0; w.bfac[b] = 1.0;
+    w.done[b] = 0; w.rowov[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0; w.nbump[b] = 0; w.lastbump[b] = 0; w.bfac[b] = 1.0;
     w.obj[b] = 1e300; w.objout[b] = 1e300; w.objprev[b] = 1e300; w.lbprev[b] = -1e300; w.lb[b] = -1e300; w.rp[b] = 1e300; w.rd[b] = 1e300;
   }
   // Gram matrix for rho = 1
@@ -556,6 +558,49 @@ __device__ __forceinline__ int jacobi_sweeps_wave16(double* Gm, double* nrm2, in
   return sweeps;
 }
 
+// Variant for the Rayleigh-Ritz matrix of k_cone_sub (order 16, nearly diagonal): tangent in fp32 (its error only slows the last
+// digits; cosine / sine in fp64 keep the rotation orthogonal) and the sweep loop ends as soon as every relative cross product of a
+// sweep was below sqrt(tau) -- the rotations of that sweep leave them below tau (quadratic convergence).
+__device__ __forceinline__ int jacobi16_fast(double* Gm, double* nrm2, int ld, double tau, int max_sweeps) {
+  const int lane = threadIdx.x & 63, grp = lane >> 3, lg = lane & 7;
+  const double tau2 = tau * tau;
+  int sweeps = 0;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    if (lane < 16) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const double x = Gm[(size_t)lane * ld + r]; a += x * x; }
+      nrm2[lane] = a;
+    }
+    WAVE_SYNC();
+    int big = 0;
+    for (int step = 0; step < 15; ++step) {
+      int p, q;
+      rr_pair(step, grp, 16, p, q);
+      double* gp = Gm + (size_t)p * ld;
+      double* gq = Gm + (size_t)q * ld;
+      const double x0 = gp[lg], x1 = gp[lg + 8], y0 = gq[lg], y1 = gq[lg + 8];
+      const double gm = group_sum_dpp<8>(x0 * y0 + x1 * y1);
+      const double a = nrm2[p], bb = nrm2[q];
+      const double g2 = gm * gm, ab = a * bb;
+      if (g2 > tau2 * ab && ab > 0.0) {
+        const float df = (float)(bb - a), gf = (float)gm;
+        const float rtf = __builtin_sqrtf(df * df + 4.0f * gf * gf);
+        const float den = (df >= 0.0f) ? (df + rtf) : (df - rtf);
+        const double tt = (den != 0.0f) ? (double)((2.0f * gf) / den) : 0.0;
+        const double cs = rsqrt(1.0 + tt * tt), sn = cs * tt;
+        gp[lg] = cs * x0 - sn * y0; gq[lg] = sn * x0 + cs * y0;
+        gp[lg + 8] = cs * x1 - sn * y1; gq[lg + 8] = sn * x1 + cs * y1;
+        if (lg == 0) { nrm2[p] = a - tt * gm; nrm2[q] = bb + tt * gm; }
+        if (g2 > tau * ab) big = 1;
+      }
+      WAVE_SYNC();
+    }
+    if (!__any(big)) { ++sweeps; break; }
+  }
+  return sweeps;
+}
+
 // generic fall-back (any N, rows not cached): used when a lane would own more than JROWS rows
 __device__ __forceinline__ int jacobi_onesided(double* Gm, int Nr, int Np, int ld, int lpp, double tau, int max_sweeps, int* s_cnt) {
   const int tid = threadIdx.x, T = blockDim.x;
@@ -823,14 +868,17 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
 // Inputs written by k_global / k_setup: Mbuf (NP16 x NP16, zero padded), fro2, Vrow (row-major V), vvalid.
 // ---------------------------------------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
+#define SUBP 16   // tracked subspace dimension of k_cone_sub
+#define SUBG 4    // Ritz values that must stay negative (guards)
 
 template <int LPP, bool USE_LDS, int RPL2, int TPB = 512>   // RPL2 = rows per lane / 2 as a compile-time constant (0: run-time bound)
 __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   extern __shared__ double smem[];
-  __shared__ int s_nsel;
+  __shared__ int s_nsel, s_nkeep, s_top[SUBP];
   __shared__ double s_base;
   const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
+  if (!w.ws_mode && w.sub_enable && w.cone_done[b]) return;      // k_cone_sub has already written W1 for this iteration
   const int n = w.n, N = n, NP = w.np16;
   const int Np = (N + 1) & ~1;
   // lane lg of a pair group owns the CONTIGUOUS rows [lg*rpl, (lg+1)*rpl): 16-byte LDS reads, rpl even, ld even
@@ -1011,6 +1059,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
       if (lamv < 0.0 || lamv > 1.0) ++ndef;
       if (lamv > 0.0) ++nkeep;
     }
+    s_nkeep = nkeep;
     int c = 0;
     if (ndef <= nkeep) {
       for (int t = 0; t < N; ++t) {
@@ -1029,6 +1078,32 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
     s_nsel = c;
   }
   __syncthreads();
+  // seed the tracked subspace (k_cone_sub) with the SUBP dominant eigenvectors when few eigenvalues are positive
+  if (w.sub_enable) {
+    const bool seed = s_nkeep <= SUBP - SUBG && N >= 3 * SUBP;
+    if (seed) {
+      if (tid == 0) {
+        for (int j = 0; j < SUBP; ++j) {
+          int bi = -1; double bl = -1e300;
+          for (int t = 0; t < N; ++t) {
+            bool used = false;
+            for (int q = 0; q < j; ++q) if (s_top[q] == t) used = true;
+            if (!used && lamv_s[t] > bl) { bl = lamv_s[t]; bi = t; }
+          }
+          s_top[j] = bi;
+          w.sub_theta[(size_t)b * SUBP + j] = bl;
+        }
+      }
+      __syncthreads();
+      double* Xg = w.Xs + (size_t)b * NP * SUBP;
+      for (int e = tid; e < SUBP * NP; e += T) {
+        const int j = e / NP, r = e - j * NP;
+        Xg[e] = (r < N) ? Gm[(size_t)s_top[j] * ld + r] * rsqrt(ev[s_top[j]]) : 0.0;
+      }
+      if (tid == 0) atomicAdd(&w.sub_stat[8 * b + 3], 1);
+    }
+    if (tid == 0) w.sub_on[b] = seed ? 1 : 0;
+  }
   for (int c2 = tid; c2 < s_nsel; c2 += T) wgt[c2] /= ev[sel[c2]];      // weight / nu^2
   __syncthreads();
   double* Wout = w.W1 + (size_t)b * n * n;
@@ -1038,6 +1113,313 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   spectral_rebuild(Gm, ld, N, sel, wgt, s_nsel, s_base, entry2, store);
   STAMP(4);
   if (tid == 0) { DIAG_CYC(2, b); DIAG_ADD(3, b, 1); }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_cone_sub: the cone block without an eigendecomposition.  clip(M, 0, 1) = sum over the eigenpairs with lambda > 0 of
+// min(lambda, 1) v v', and once the ADMM iterate has settled M = Y - D1 has only a handful of positive eigenvalues (config 2:
+// 2 of 100; the other 98 carry the scaled dual of Y >= 0).  The slot therefore follows the dominant invariant subspace with a
+// block X of SUBP = 16 orthonormal vectors, warm-started from the previous ADMM iteration:
+//     `chunk` steps of  X <- orth((M + s I) X)   (v_mfma_f64_16x16x4_f64 for M X and the Gram matrix, Cholesky-QR),
+//     Rayleigh-Ritz on the 16 x 16 projection (in-wave Jacobi), residuals || M x - theta x || of every Ritz pair with theta >= 0;
+//     accepted when they are below sub_tol ||M||_F and at least SUBG Ritz values are negative (so that no positive eigenvalue
+//     hides outside the block); otherwise more steps, and after sub_qmax steps the slot falls back to the full kernel.
+// The shift s centres the untracked spectrum [lo, theta_min]; lo comes from the first two moments of M (trace and Frobenius
+// norm, written by k_global) by Samuelson's inequality, so it is a rigorous bound, not a guess.
+// One 256-thread workgroup per slot, ~38 KB of LDS: four workgroups per CU.  The full kernel (k_cone_ws) seeds X from its
+// eigenvectors whenever it finds at most SUBP - SUBG positive eigenvalues.
+// ---------------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
+  extern __shared__ double smem[];
+  __shared__ int s_flag, s_nsel;
+  __shared__ double s_shift;
+  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
+  if (w.done[b] || !w.sub_on[b]) return;
+  if (w.sub_wait[b] > 0) { if (threadIdx.x == 0) w.sub_wait[b] -= 1; return; }     // backing off after a failed call
+  const int n = w.n, NP = w.np16, nt = NP >> 4, LD = NP + 2;
+  const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  double* Xa = smem;                     // SUBP x LD   X (column j at Xa + j*LD)
+  double* Za = Xa + (size_t)SUBP * LD;   // SUBP x LD   Z = M X, then Y = Z + s X
+  double* Cs = Za + (size_t)SUBP * LD;   // 4 partial 16 x 16 products
+  double* Hs = Cs + 4 * 256;             // 16 x 17: Gram matrix / Cholesky factor / H / Ritz rotation
+  double* Gj = Hs + 16 * 17;             // 16 x 17: Jacobi work
+  double* th = Gj + 16 * 17;             // 16 Ritz values
+  double* evj = th + 16;                 // 16 squared norms
+  double* red = evj + 16;                // 32
+  double* wgt = red + 32;                // 16
+  int* sel = (int*)(wgt + 16);           // 16
+  const double* Mb = w.Mbuf + (size_t)b * NP * NP;
+  double* Xg = w.Xs + (size_t)b * NP * SUBP;
+  const double fro2 = w.fro2[b], nF = sqrt(fro2), trM = w.trM[b];
+  // inexact projections are harmless while the ADMM iterate itself still moves (errors proportional to the step are summable):
+  // the residual target follows the last dual residual ||Y_new - Y_old|| down to sub_tol
+  const double tol_eff = (w.sub_adapt > 0.0) ? fmin(1e-6, fmax(w.sub_tol, w.sub_adapt * w.rd[b] / fmax(nF, 1e-300))) : w.sub_tol;
+  for (int e = tid; e < SUBP * NP; e += T) { const int j = e / NP, r = e - j * NP; Xa[(size_t)j * LD + r] = Xg[e]; }
+  if (tid < SUBP) th[tid] = w.sub_theta[(size_t)b * SUBP + tid];
+  __syncthreads();
+
+  // Z (+ s X) = M X for the row tiles of this wave (up to three, computed together: independent accumulators and twelve loads in
+  // flight per lane); operands: M from L2 (symmetric: column k of M is row k), X from LDS
+  auto mul_MX = [&](double shift) {
+    const int t0 = wv, t1 = (wv + 4 < nt) ? wv + 4 : wv, t2 = (wv + 8 < nt) ? wv + 8 : wv;     // invalid tiles alias tile wv (results dropped)
+    const bool v1 = wv + 4 < nt, v2 = wv + 8 < nt;
+    double4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0;
+    const double* M0 = Mb + (t0 << 4) + li;
+    const double* M1 = Mb + (t1 << 4) + li;
+    const double* M2 = Mb + (t2 << 4) + li;
+    const double* Xb = Xa + (size_t)li * LD;
+    double a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const size_t o = (size_t)(4 * u + lk) * NP; a0[u] = M0[o]; a1[u] = M1[o]; a2[u] = M2[o]; }
+    for (int k0 = 0; k0 < NP; k0 += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double x0 = a0[u], x1 = a1[u], x2 = a2[u], bv = Xb[k0 + 4 * u + lk];
+        int kn = k0 + 16 + 4 * u + lk;
+        kn = (kn < NP) ? kn : kn - NP;               // wrapped prefetch of the last chunk is never used
+        const size_t o = (size_t)kn * NP;
+        a0[u] = M0[o]; a1[u] = M1[o]; a2[u] = M2[o];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, bv, acc1, 0, 0, 0);
+        if (nt > 8) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, bv, acc2, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t a = (size_t)li * LD + lk + 4 * r;
+      Za[a + (t0 << 4)] = acc0[r] + shift * Xa[a + (t0 << 4)];
+      if (v1) Za[a + (t1 << 4)] = acc1[r] + shift * Xa[a + (t1 << 4)];
+      if (v2) Za[a + (t2 << 4)] = acc2[r] + shift * Xa[a + (t2 << 4)];
+    }
+  };
+  // Hs = P' Q (16 x 16) for two SUBP x LD blocks: the rows are split over the four waves, partial tiles summed in a fixed order
+  auto gram = [&](const double* P, const double* Q) {
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    const double* Pa = P + (size_t)li * LD;
+    const double* Qa = Q + (size_t)li * LD;
+    for (int u = wv; u < (NP >> 2); u += 4) {
+      const int row = 4 * u + lk;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pa[row], Qa[row], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cs[wv * 256 + (lk + 4 * r) * 16 + li] = acc[r];
+    __syncthreads();
+    Hs[(tid >> 4) * 17 + (tid & 15)] = (Cs[tid] + Cs[256 + tid]) + (Cs[512 + tid] + Cs[768 + tid]);
+    __syncthreads();
+  };
+
+  int steps = 0, ok = 0, fail = 0, nrr = 0;
+  const int qmax = w.sub_qmax, chunk = w.sub_chunk;
+  const bool prof = (w.sub_debug == 2) && b == 0;
+  long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0;
+#define SUBSTAMP(slot) do { if (prof) { __syncthreads(); if (tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); w.stamps[slot] += (double)(t_ - tprev); tprev = t_; } } } while (0)
+  SUBSTAMP(0);
+  while (true) {
+    // ---- `chunk` power steps with the shift that centres the untracked part of the spectrum --------------------------------
+    if (wv == 0) {
+      const double tj = (lane < SUBP) ? th[lane] : 0.0;
+      const double st = wave_sum(tj), st2 = wave_sum(tj * tj);
+      const double nr = (double)(n - SUBP);
+      const double mu = (trM - st) / nr;
+      const double var = fmax((fro2 - st2) / nr - mu * mu, 0.0);
+      // The untracked spectrum lies in [lo, hi].  hi = the smallest Ritz value on the upper side (above the mean mu of the untracked
+      // eigenvalues).  lo: Samuelson's inequality (every untracked eigenvalue is >= mu - sigma sqrt(nr - 1)) is rigorous but several
+      // times too low when the bottom is a tight cluster (the scaled dual of Y >= 0), so mu - 3 sigma is used when it is the larger
+      // one; a block vector that the iteration has pulled to the BOTTOM of the spectrum (Ritz value below mu: the shift was too small)
+      // is itself the best estimate of lambda_min and takes precedence.  A wrong estimate costs steps, never accuracy (residual test).
+      double hi = (lane < SUBP && tj > mu) ? tj : 1e300, lo_t = (lane < SUBP && !(tj > mu)) ? tj : 1e300;
+      for (int o = 32; o > 0; o >>= 1) { hi = fmin(hi, __shfl_xor(hi, o, WAVE)); lo_t = fmin(lo_t, __shfl_xor(lo_t, o, WAVE)); }
+      if (hi > 1e299) hi = mu;
+      double lo = fmax(mu - sqrt(var * (nr - 1.0)), mu - 3.0 * sqrt(var));
+      if (lo_t < 1e299) lo = fmin(lo, lo_t - 0.05 * (hi - lo_t));
+      if (lane == 0) s_shift = -0.5 * (lo + hi);
+    }
+    __syncthreads();
+    const double shift = s_shift;
+    SUBSTAMP(1);
+    for (int c = 0; c < chunk && !fail; ++c) {
+      mul_MX(shift);
+      __syncthreads();
+      SUBSTAMP(2);
+      gram(Za, Za);
+      SUBSTAMP(3);
+      if (wv == 0) {
+        // Cholesky of the Gram matrix in REGISTERS: lane i < 16 holds row i, pivots and multipliers travel by v_readlane (no LDS
+        // round trips, no barrier); then column j of L^-1 by forward substitution in lane j.  ~1.5 k instructions, one wave.
+        double c[SUBP];
+        const int i = (lane < SUBP) ? lane : SUBP - 1;
+#pragma unroll
+        for (int q = 0; q < SUBP; ++q) c[q] = Hs[i * 17 + q];
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < SUBP; ++j) {
+          const double d = readlane_d(c[j], j);
+          if (!(d > 1e-280)) bad = 1;
+          const double inv = rsqrt(fmax(d, 1e-280));
+          const double lj = c[j] * inv;                 // L[i][j] for i >= j (lane j: sqrt(d))
+#pragma unroll
+          for (int q = j + 1; q < SUBP; ++q) c[q] = fma(-lj, readlane_d(lj, q), c[q]);
+          c[j] = lj;
+        }
+        if (lane < SUBP) {
+#pragma unroll
+          for (int q = 0; q < SUBP; ++q) Gj[lane * 17 + q] = (q <= lane) ? c[q] : 0.0;      // L (lower triangle) -> Gj
+        }
+        WAVE_SYNC();
+        // L^-1: lane j solves L z = e_j; the result goes to Hs as Linv[i][j]
+        double z[SUBP];
+#pragma unroll
+        for (int r = 0; r < SUBP; ++r) {
+          double v = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+          for (int q = 0; q < SUBP; ++q) if (q < r) v = fma(-Gj[r * 17 + q], z[q], v);
+          z[r] = v / Gj[r * 17 + r];
+        }
+        WAVE_SYNC();
+        if (lane < SUBP) {
+#pragma unroll
+          for (int r = 0; r < SUBP; ++r) Hs[r * 17 + lane] = (r >= lane) ? z[r] : 0.0;       // Linv[r][j = lane]
+        }
+        if (lane == 0) s_flag = bad;
+      }
+      __syncthreads();
+      SUBSTAMP(4);
+      if (s_flag) { fail = 3; break; }
+      {   // X = Y L^-T by MFMA: X[row][j] = sum_q Y[row][q] Linv[j][q]
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int ti = wv + 4 * q, i0 = ti << 4;
+          if (ti < nt) {
+            double4v a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], Hs[li * 17 + 4 * u + lk], a1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xa[(size_t)li * LD + i0 + lk + 4 * r] = a1[r];
+          }
+        }
+      }
+      __syncthreads();
+      SUBSTAMP(5);
+      ++steps;
+    }
+    if (fail) break;
+    // ---- Rayleigh-Ritz ------------------------------------------------------------------------------------------------------
+    mul_MX(0.0);
+    __syncthreads();
+    gram(Xa, Za);
+    SUBSTAMP(6);
+    {   // symmetrised H + sigma I -> Gj (sigma = 1.5 ||H||_F makes it positive definite), one-sided Jacobi inside wave 0
+      const int i = tid >> 4, j = tid & 15;
+      const double hv = 0.5 * (Hs[i * 17 + j] + Hs[j * 17 + i]);
+      const double f2 = block_sum(hv * hv, red);
+      if (tid == 0) s_shift = 1.5 * sqrt(f2) + 1e-300;
+      __syncthreads();
+      Gj[j * 17 + i] = hv + ((i == j) ? s_shift : 0.0);
+      __syncthreads();
+      if (wv == 0) {
+        jacobi16_fast(Gj, evj, 17, 1e-13, 12);
+        if (lane < 16) { double a = 0.0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const double x = Gj[lane * 17 + r]; a += x * x; }
+          evj[lane] = a; }
+      }
+      __syncthreads();
+    }
+    const double sigma = s_shift;
+    if (tid < SUBP) th[tid] = sqrt(evj[tid]) - sigma;
+    __syncthreads();
+    SUBSTAMP(7);
+    Hs[(tid >> 4) * 17 + (tid & 15)] = Gj[(tid & 15) * 17 + (tid >> 4)] * rsqrt(evj[tid & 15]);    // Wr[k][t] = g_t[k] / nu_t
+    __syncthreads();
+    {   // X <- X Wr, Z <- Z Wr (results held in registers until every wave has finished reading; <= 3 row tiles per wave: NP <= 192)
+      double4v ax[3], az[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int ti = wv + 4 * q, i0 = ti << 4;
+        double4v a1 = {0.0, 0.0, 0.0, 0.0}, a2 = {0.0, 0.0, 0.0, 0.0};
+        if (ti < nt) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double bw = Hs[(4 * u + lk) * 17 + li];
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[(size_t)(4 * u + lk) * LD + i0 + li], bw, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], bw, a2, 0, 0, 0);
+          }
+        }
+        ax[q] = a1; az[q] = a2;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int ti = wv + 4 * q, i0 = ti << 4;
+        if (ti < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const size_t a = (size_t)li * LD + i0 + lk + 4 * r; Xa[a] = ax[q][r]; Za[a] = az[q][r]; }
+        }
+      }
+      __syncthreads();
+    }
+    SUBSTAMP(8);
+    // residuals of the Ritz pairs: wave wv handles columns 4 wv .. 4 wv + 3
+    for (int c = 0; c < 4; ++c) {
+      const int t = 4 * wv + c;
+      const double tv = th[t];
+      double a = 0.0;
+      for (int r = lane; r < NP; r += WAVE) { const double d = Za[(size_t)t * LD + r] - tv * Xa[(size_t)t * LD + r]; a += d * d; }
+      a = wave_sum(a);
+      if (lane == 0) evj[t] = sqrt(a);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      // a Ritz pair (theta, x) contaminated by an untracked eigenvector (eigenvalue <= gneg < 0) by an angle phi has residual
+      // ~ (theta - gneg) phi and perturbs W1 by ~ theta phi: pairs with a small theta may carry a proportionally larger residual
+      int nk = 0, bad = 0; double gneg = -1e300;
+      for (int t = 0; t < SUBP; ++t) { if (th[t] > 0.0) ++nk; else gneg = fmax(gneg, th[t]); }
+      if (gneg < -1e299) gneg = 0.0;
+      for (int t = 0; t < SUBP; ++t) {
+        if (th[t] > -1e-9 * nF) {      // (nearly) positive Ritz values must be accurate
+          const double scale = (th[t] > 0.0) ? 1.0 + fmin(-gneg / th[t], 1e6) : 1.0;
+          if (!(evj[t] <= tol_eff * nF * scale)) bad = 1;
+        }
+      }
+      s_flag = (nk > SUBP - SUBG) ? 2 : (bad ? 0 : 1);
+    }
+    __syncthreads();
+    SUBSTAMP(9);
+    ++nrr;
+    if (s_flag == 2) { fail = 1; break; }
+    if (s_flag == 1) { ok = 1; break; }
+    if (steps >= qmax) {
+      if (w.sub_debug == 1 && tid < SUBP) { w.stamps[tid] = th[tid]; w.stamps[16 + tid] = evj[tid] / nF; }     // diagnostics: the Ritz values / relative residuals that did not make it
+      fail = 2; break;
+    }
+  }
+  if (tid == 0) {
+    atomicAdd(&w.sub_stat[8 * b + 0], 1); atomicAdd(&w.sub_stat[8 * b + 1], steps); atomicAdd(&w.sub_stat[8 * b + 7], nrr);
+    if (!ok) {
+      atomicAdd(&w.sub_stat[8 * b + 2], 1); atomicAdd(&w.sub_stat[8 * b + 3 + fail], 1);   // 4: too many positive Ritz values, 5: step cap, 6: Cholesky
+      const int nf = w.sub_nfail[b] + 1;          // exponential back-off: the spectrum still moves too fast for the tracked block
+      w.sub_nfail[b] = nf; w.sub_wait[b] = (nf >= 7) ? 128 : (1 << nf);
+    }
+  }
+  if (!ok) return;                       // cone_done stays 0: the full kernel projects this slot (and re-seeds X)
+  for (int e = tid; e < SUBP * NP; e += T) { const int j = e / NP, r = e - j * NP; Xg[e] = Xa[(size_t)j * LD + r]; }
+  if (tid < SUBP) w.sub_theta[(size_t)b * SUBP + tid] = th[tid];
+  if (tid == 0) {
+    int c = 0;
+    for (int t = 0; t < SUBP; ++t) if (th[t] > 0.0) { sel[c] = t; wgt[c] = fmin(th[t], 1.0); ++c; }
+    s_nsel = c;
+  }
+  __syncthreads();
+  double* Wout = w.W1 + (size_t)b * n * n;
+  auto entry0 = [&](int, int) { return 0.0; };
+  auto store = [&](int i, int j, double v, double) { Wout[(size_t)j * n + i] = v; Wout[(size_t)i * n + j] = v; };
+  SUBSTAMP(10);
+  spectral_rebuild(Xa, LD, n, sel, wgt, s_nsel, 0.0, entry0, store);
+  SUBSTAMP(11);
+  if (prof && tid == 0) { w.stamps[12] += 1.0; w.stamps[13] += steps; w.stamps[14] += nrr; }
+  if (tid == 0) w.cone_done[b] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1377,7 +1759,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   __syncthreads();
   STAMP(10);
   // 4. multipliers (mu = lam / rho)
-  if (tid < WAVE) wave_nnqp(w.G + (size_t)b * w.Rmax * w.Rmax, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid);
+  if (tid < WAVE) { const int ov = wave_nnqp(w.G + (size_t)b * w.Rmax * w.Rmax, w.Rmax, cvec, mu, R, s_Gp, s_sv, s_tmp, s_pl, tid); if (tid == 0) w.rowov[b] = ov; }
   __syncthreads();
   for (int e = tid; e < R; e += T) lam[e] = rho * mu[e];
   STAMP(11);
@@ -1389,7 +1771,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     tU[e] = 0.5 * corr;
   }
   __syncthreads();
-  double rp2 = 0.0, rd2 = 0.0, fr2 = 0.0;
+  double rp2 = 0.0, rd2 = 0.0, fr2 = 0.0, tr1 = 0.0;
   const int NP = w.np16;
   double* Mb = w.Mbuf + (size_t)b * NP * NP;
   for (int e = tid; e < r * k; e += T) {
@@ -1448,6 +1830,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     const double mv = yn - d1n;                        // next input of the cone block
     Mb[(size_t)j * NP + i] = mv;
     fr2 += mv * mv;
+    if (i == j) tr1 += mv;
     rp2 += (w1 - yn) * (w1 - yn) + (w3y - yn) * (w3y - yn);
     rd2 += (yn - yold) * (yn - yold);
     Yp[a1] = yold; Y[a1] = yn;
@@ -1456,7 +1839,8 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   rp2 = block_sum(rp2, red);
   rd2 = block_sum(rd2, red);
   fr2 = block_sum(fr2, red);
-  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.fro2[b] = fr2; w.iters[b] += 1; DIAG_CYC(4, b); }
+  tr1 = block_sum(tr1, red);
+  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.fro2[b] = fr2; w.trM[b] = tr1; w.cone_done[b] = 0; w.iters[b] += 1; DIAG_CYC(4, b); }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1552,8 +1936,10 @@ __global__ void k_check_final(OmcWS w, int last) {
   const double obj = w.obj[b];
   w.objout[b] = obj;
   const double Nk = (double)(w.n + w.k);
-  const bool feas = w.rp[b] <= w.eps_feas * sqrt(Nk);
-  if ((obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && feas) { w.done[b] = 1; w.status[b] = OMC_ST_OPTIMAL; return; }
+  const bool feas = w.rp[b] <= w.eps_feas * sqrt(Nk) && !w.rowov[b];   // rows deferred by the NNQP cap: not a feasible point
+  // two-sided: the primal value of an eps-feasible iterate can sit BELOW the certified bound (by ~ residual x ||multipliers||); such a
+  // point is not within eps_gap of the optimum value, so the node keeps iterating until feasibility has pulled the value up
+  if (fabs(obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && feas) { w.done[b] = 1; w.status[b] = OMC_ST_OPTIMAL; return; }
   // f(Y) <= f(0) = 1/2 ||A_Omega||^2 on the feasible set: a larger certified bound proves infeasibility
   if (w.lb[b] > 0.5 * w.sumA2 * (1.0 + 1e-9) + 1e-9) { w.done[b] = 1; w.status[b] = OMC_ST_INFEASIBLE; return; }
   // stationary primal value and no progress of the bound: give up with values (MOI.SLOW_PROGRESS)
@@ -1561,7 +1947,7 @@ __global__ void k_check_final(OmcWS w, int last) {
   else w.stall[b] = 0;
   w.objprev[b] = obj; w.lbprev[b] = w.lb[b];
   if (w.stall[b] >= w.stall_checks) {
-    const bool okgap = (obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && w.rp[b] <= 10.0 * w.eps_feas * sqrt(Nk);
+    const bool okgap = fabs(obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && w.rp[b] <= 10.0 * w.eps_feas * sqrt(Nk) && !w.rowov[b];
     w.done[b] = 1; w.status[b] = okgap ? OMC_ST_OPTIMAL : OMC_ST_SLOW; return;
   }
   if (last) { w.done[b] = 1; w.status[b] = last; return; }
@@ -1587,15 +1973,16 @@ __global__ void __launch_bounds__(256) k_rho_rescale(OmcWS w) {
   for (int e = tid; e < k * k; e += T) w.D3T[(size_t)b * k * k + e] *= inv;
   // the cone input buffer holds Y - D1: rebuild it with the rescaled dual
   const int NP = w.np16;
-  double fr2 = 0.0;
+  double fr2 = 0.0, tr1 = 0.0;
   __shared__ double red[32];
   for (int e = tid; e < n * n; e += T) {
     const int i = e % n, j = e / n;
     const double mv = w.Y[(size_t)b * n * n + e] - w.D1[(size_t)b * n * n + e];
-    w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
+    w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv; if (i == j) tr1 += mv;
   }
   fr2 = block_sum(fr2, red);
-  if (tid == 0) { w.fro2[b] = fr2; w.bfac[b] = 1.0; if (w.accel && w.aa_valid[b] != 2) w.aa_valid[b] = 0; }   // the map changed: restart the history
+  tr1 = block_sum(tr1, red);
+  if (tid == 0) { w.fro2[b] = fr2; w.trM[b] = tr1; w.bfac[b] = 1.0; if (w.accel && w.aa_valid[b] != 2) w.aa_valid[b] = 0; }   // the map changed: restart the history
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1628,14 +2015,15 @@ __global__ void __launch_bounds__(512) k_aa(OmcWS w) {
   auto rebuild_cone_input = [&]() {   // Mbuf = Y - D1 (zero padded), fro2
     __syncthreads();
     const int NP = w.np16;
-    double fr2 = 0.0;
+    double fr2 = 0.0, tr1 = 0.0;
     for (int e = tid; e < n * n; e += T) {
       const int i = e % n, j = e / n;
       const double mv = seg[0].p[e] - seg[2].p[e];
-      w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
+      w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv; if (i == j) tr1 += mv;
     }
     fr2 = block_sum(fr2, red);
-    if (tid == 0) w.fro2[b] = fr2;
+    tr1 = block_sum(tr1, red);
+    if (tid == 0) { w.fro2[b] = fr2; w.trM[b] = tr1; }
   };
   if (!w.aa_valid[b]) {   // first use, new node or a penalty bump: zin = state, empty history
     int o = 0;
@@ -1883,6 +2271,10 @@ void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, 
     else hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->nB), dim3(512), 0, s, *w);
   }
 }
+size_t omc_cone_sub_lds(int np16) { return ((size_t)2 * SUBP * (np16 + 2) + 4 * 256 + 2 * 16 * 17 + 16 + 16 + 32 + 16 + 8) * sizeof(double); }
+void omc_launch_cone_sub(const OmcWS* w, hipStream_t s) {
+  hipLaunchKernelGGL(k_cone_sub, dim3(w->nB), dim3(256), omc_cone_sub_lds(w->np16), s, *w);
+}
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
   if (use_lds) hipLaunchKernelGGL(k_small<true>, dim3(w->nB), dim3(256), lds_bytes, s, *w, mode);
   else hipLaunchKernelGGL(k_small<false>, dim3(w->nB), dim3(256), 0, s, *w, mode);
@@ -1909,9 +2301,10 @@ void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* 
 }
 int omc_set_max_lds(void) {
   hipError_t e1 = hipFuncSetAttribute((const void*)k_cone<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  hipError_t e2 = hipFuncSetAttribute((const void*)k_global<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  hipError_t e2 = hipFuncSetAttribute((const void*)k_global<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS - 8 * 1024);   // ~19 KB of static LDS (NNQP scratch)
   hipError_t e3 = hipFuncSetAttribute((const void*)k_colprox, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e4 = hipFuncSetAttribute((const void*)k_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_sub, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
 #define WS_ATTR(L, R) (void)hipFuncSetAttribute((const void*)k_cone_ws<L, true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS)
 #define WS_ATTR_ALL(L) WS_ATTR(L, 0); WS_ATTR(L, 4); WS_ATTR(L, 5); WS_ATTR(L, 6); WS_ATTR(L, 7); WS_ATTR(L, 8)
   WS_ATTR_ALL(4); WS_ATTR_ALL(8); WS_ATTR_ALL(16);

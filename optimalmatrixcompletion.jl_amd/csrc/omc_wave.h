@@ -241,14 +241,17 @@ __device__ __forceinline__ void wave_chol_solve(const double* Lm, int c, const d
 // previous multipliers).  G is R x R (ld = Rmax) in global memory; the passive-set system (<= NNQP_PMAX) is
 // solved by Cholesky in LDS with a tiny ridge (parallel rows make G singular).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_nnqp(const double* G, int ldG, const double* cvec, double* lam, int R, double* Gp, double* sv,
+// Returns 1 (wave-uniform) when the passive set hit NNQP_PMAX with a violated row still outside it -- the result is then NOT the
+// exact projection and the caller must not certify / accept the point (relaxation: no OPTIMAL status; altmin: converged = false).
+__device__ __forceinline__ int wave_nnqp(const double* G, int ldG, const double* cvec, double* lam, int R, double* Gp, double* sv,
                           double* tmp, int* plist, int lane) {
   // plist: passive indices (LDS, NNQP_PMAX ints); Gp: PMAX x (PMAX+1); sv,tmp: PMAX doubles
   int np = 0;
+  int overflow = 0;
   // warm start: passive = {lam > 0}
   for (int r = 0; r < R; ++r) {  // uniform over the wave (lam in LDS/global, same for all lanes)
     if (lam[r] > 0.0 && np < NNQP_PMAX) { if (lane == 0) plist[np] = r; ++np; }
-    else if (lam[r] != 0.0) { if (lane == 0) lam[r] = 0.0; }
+    else if (lam[r] != 0.0) { if (lam[r] > 0.0) overflow = 1; if (lane == 0) lam[r] = 0.0; }
   }
   WAVE_SYNC();
   double cmax = 0.0;
@@ -272,7 +275,8 @@ __device__ __forceinline__ void wave_nnqp(const double* G, int ldG, const double
         double ob = __shfl_xor(best, o, WAVE); int oi = __shfl_xor(bi, o, WAVE);
         if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
       }
-      if (bi < 0 || best <= tol || np >= NNQP_PMAX) break;
+      if (bi < 0 || best <= tol) { overflow = 0; break; }      // every row satisfied: whatever was dropped at the warm start is not needed
+      if (np >= NNQP_PMAX) { overflow = 1; break; }
       if (lane == 0) plist[np] = bi;
       ++np;
       WAVE_SYNC();
@@ -339,6 +343,7 @@ __device__ __forceinline__ void wave_nnqp(const double* G, int ldG, const double
       if (np == 0) break;
     }
   }
+  return overflow;
 }
 
 #endif

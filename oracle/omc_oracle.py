@@ -713,7 +713,8 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
             lb_new = dual_bound_from(inst, Lam, rows, lam, Q, rho * Q3)
             lb = max(lb, lb_new)
             hist.append((it, obj, lb, rp, rd, rho))
-            if (obj - lb) <= p.eps_gap * max(1.0, abs(obj)) and rp <= p.eps_feas * math.sqrt(n + k):
+            # two-sided: an eps-feasible iterate can sit below the certified bound; that is not a certificate of eps_gap accuracy
+            if abs(obj - lb) <= p.eps_gap * max(1.0, abs(obj)) and rp <= p.eps_feas * math.sqrt(n + k):
                 status = OMC_OPTIMAL
                 break
             if lb > 0.5 * inst.sumA2 * (1.0 + 1e-9) + 1e-9:   # f(Y) <= f(0) = 1/2||A_Omega||^2 for feasible Y
@@ -725,7 +726,7 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
                 stall = 0
             obj_prev = obj; lb_prev = lb
             if stall >= p.stall_checks:
-                if (obj - lb) <= p.eps_gap * max(1.0, abs(obj)) and rp <= 10.0 * p.eps_feas * math.sqrt(n + k):
+                if abs(obj - lb) <= p.eps_gap * max(1.0, abs(obj)) and rp <= 10.0 * p.eps_feas * math.sqrt(n + k):
                     status = OMC_OPTIMAL                               # certified gap, residual within 10x of its target
                 break                                                  # else SLOW_PROGRESS, values available
             if time.time() - t0 > p.time_limit:
@@ -802,6 +803,10 @@ def _proj_psd(M):
 # ----------------------------------------------------------------------------------------------------------
 # alternating minimisation  (OMC.jl:1979-2279)
 # ----------------------------------------------------------------------------------------------------------
+AM_MAX_DOUBLINGS = 64      # bracket search of the ball multiplier in the rank-1 U-step (same constant in omc_altmin.hip)
+AM_FEAS_TOL = 1e-6         # largest constraint violation accepted from a U-step; beyond it model_U is reported as failed
+
+
 def altmin_v_step(inst, U):
     """model_V (OMC.jl:2193-2208): unconstrained; per column j
        (sum_{i in O_j} u_i u_i' + U'U/gamma) V_j = sum_{i in O_j} u_i A_ij."""
@@ -952,9 +957,9 @@ def altmin_u_step(inst, V, cuts=(), cut_type="linear", U_lower=None, U_upper=Non
         theta = 0.0
         if u @ u > 1.0:
             lo_t, hi_t = 0.0, max(1.0, float(np.abs(gg).max()))
-            while True:
+            for _dbl in range(AM_MAX_DOUBLINGS + 1):   # capped: an infeasible model_U never enters the ball (k_altmin does the same)
                 u, lam = solve_theta(hi_t)
-                if u @ u <= 1.0:
+                if u @ u <= 1.0 or _dbl == AM_MAX_DOUBLINGS:
                     break
                 hi_t *= 2.0
             for _ in range(200):
@@ -970,10 +975,17 @@ def altmin_u_step(inst, V, cuts=(), cut_type="linear", U_lower=None, U_upper=Non
             u, lam = solve_theta(theta)
         Un = u.reshape(n, 1)
         obj = 0.5 * float((h * u * u).sum()) - float(gg @ u) + const
-        return Un, obj, dict(theta=theta, lam=lam, rows=[rows.kinds[r] for r in sel])
+        viol = max(float((C @ u - d).max()) if len(sel) else 0.0, float(u @ u) - 1.0)
+        return Un, obj, dict(theta=theta, lam=lam, rows=[rows.kinds[r] for r in sel], violation=viol)
     # ---- k > 1 -----------------------------------------------------------------------------------------
     if method == "dual":
-        return _ustep_dual_newton(H, gv, C.reshape(len(sel), n, k), d, const)
+        Un, obj, info = _ustep_dual_newton(H, gv, C.reshape(len(sel), n, k), d, const)
+        Wq, rad = quadratic_constraint_vectors(k)
+        viol = float((((Un @ Wq.T) ** 2).sum(0) - rad).max())
+        if len(sel):
+            viol = max(viol, float((C @ Un.ravel() - d).max()))
+        info["violation"] = viol
+        return Un, obj, info
     from scipy.optimize import minimize
 
     def q(u):
@@ -1031,8 +1043,10 @@ def alternating_minimization(inst, U_initial, cuts=(), cut_type="linear", U_lowe
     while counter < max_iters and time.time() - t0 < time_limit:                # OMC.jl:2186-2189
         counter += 1
         V_new = altmin_v_step(inst, U_current)                                 # 2192-2209
-        U_new, objective_new, _ = altmin_u_step(inst, V_new, cuts, cut_type, U_lower, U_upper,
-                                                reference_quirk_q1)            # 2212-2232
+        U_new, objective_new, info = altmin_u_step(inst, V_new, cuts, cut_type, U_lower, U_upper,
+                                                   reference_quirk_q1)         # 2212-2232
+        if not (info.get("violation", 0.0) <= AM_FEAS_TOL):
+            break                  # model_U had no solution: the reference's try/catch -> break, converged = false (2231, 2263-2265)
         objectives.append(objective_new)
         objective_diff = abs((objective_new - objective_current) / objective_current)
         if objective_diff < eps:                                               # 2235
