@@ -57,6 +57,7 @@ extern "C" {
 #define OMC_ERR_ARGUMENT (-3)
 #define OMC_ERR_UNSUPPORTED (-4)    /* valid in the reference, not built yet (see DESIGN.md scope table) */
 #define OMC_ERR_NO_DEVICE (-5)
+#define OMC_ERR_COMM (-6)           /* RCCL not loadable / communicator not initialised / a collective failed */
 
 typedef struct omc_instance omc_instance; /* opaque handle: device copies of A, mask, index lists, workspaces */
 
@@ -149,6 +150,10 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
                      double eps, int max_iters, double time_limit, double* U, double* V, int* converged,
                      int* n_iters, double* objectives, double* solve_time);
 
+/* evaluate_objective(U * V) of the LAST omc_altmin_batch call (OMC.jl:920 `X_local = U * V`, 925-927), computed on the device from the
+ * factors inside the altmin kernel: the driver compares it with the incumbent without forming X; X is built for the winner only. */
+int omc_altmin_master_objectives(omc_instance* h, int B, double* objective);
+
 /* ---- evaluate_objective (OMC.jl:2330-2359) for B matrices X (n*m each) --------------------------------- */
 int omc_evaluate_objective(omc_instance* h, int B, const double* X, double* objective);
 
@@ -178,6 +183,23 @@ int omc_violated_shor_minors(omc_instance* h, const double* X, int n_classes, co
                              int64_t* minors, int* n_out);
 /* device milliseconds and candidate count of the last omc_shor_indexes / omc_violated_shor_minors call */
 int omc_shor_last_stats(omc_instance* h, double* ms, int64_t* candidates);
+
+/* ---- multi-GPU: node-parallel B&B, one process per GPU ------------------------------------------------------
+ * Nodes are independent given (A, indices, gamma): every rank holds its own omc_instance on its own device and relaxes its shard
+ * of the popped nodes.  The only exchange of the loop (OMC.jl:700-1073: tree.best_upper_bound at 725 / 797 / 1225, the global
+ * lower bound at 1207-1218) is a 16-byte MIN all-reduce of {incumbent upper bound, smallest open lower bound} per round, and --
+ * only when the incumbent improved -- a broadcast of the new X from the rank that found it.  RCCL (librccl, loaded on first use)
+ * over xGMI; the communicator lives in the handle.
+ *   omc_comm_unique_id   : rank 0 creates the 128-byte id; the host language distributes it to the other ranks (any channel).
+ *   omc_comm_init        : collective over all ranks, after every rank has created its instance on its device.
+ *   omc_allreduce_bounds : in place; *owner (may be NULL) = smallest rank whose local ub equals the global minimum.
+ *   omc_bcast_incumbent  : X (n*m, column-major) from rank `root` to every rank.                                                */
+#define OMC_COMM_ID_BYTES 128
+int omc_comm_unique_id(void* id_out);
+int omc_comm_init(omc_instance* h, int rank, int world_size, const void* id);
+int omc_allreduce_bounds(omc_instance* h, double* ub, double* lb, int* owner);
+int omc_bcast_incumbent(omc_instance* h, int root, double* X);
+int omc_comm_destroy(omc_instance* h);
 
 /* per-kernel accounting of the last omc_relax_solve: launches and HIP-event milliseconds per kernel class */
 #define OMC_KERNEL_COLPROX 0

@@ -16,6 +16,7 @@ EXPORTS = [
     "omc_relax_fetch", "omc_altmin_batch", "omc_evaluate_objective", "omc_separation_batch", "omc_round_Y_batch",
     "omc_last_kernel_stats", "omc_last_solver_info", "omc_last_subspace_stats", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
     "omc_shor_count", "omc_shor_indexes", "omc_violated_shor_minors", "omc_shor_last_stats",
+    "omc_altmin_master_objectives", "omc_comm_unique_id", "omc_comm_init", "omc_allreduce_bounds", "omc_bcast_incumbent", "omc_comm_destroy",
 ]
 
 
@@ -74,6 +75,12 @@ def load():
     lib.omc_shor_indexes.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp]
     lib.omc_violated_shor_minors.argtypes = [vp, vp, C.c_int, vp, C.c_int64, vp, C.c_int, vp, vp, vp]
     lib.omc_shor_last_stats.argtypes = [vp, vp, vp]
+    lib.omc_altmin_master_objectives.argtypes = [vp, C.c_int, vp]
+    lib.omc_comm_unique_id.argtypes = [vp]
+    lib.omc_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.omc_allreduce_bounds.argtypes = [vp, vp, vp, vp]
+    lib.omc_bcast_incumbent.argtypes = [vp, C.c_int, vp]
+    lib.omc_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib
 

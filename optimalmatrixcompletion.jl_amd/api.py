@@ -155,6 +155,30 @@ class Engine:
         return dict(solve_seconds=info[0], jacobi_sweeps=int(info[1]), rho=info[2], r_max=int(info[3]), cone_lds=bool(info[4]),
                     global_lds=bool(info[5]), small_lds=bool(info[6]), R_max=int(info[7]))
 
+    # ---- multi-GPU exchange behind the C ABI (RCCL) ------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id, created by rank 0 and handed to every rank by the host (torch.distributed, MPI, a file ...)."""
+        buf = np.zeros(128, np.uint8)
+        _lib.check(_lib.load().omc_comm_unique_id(_lib.ptr(buf)))
+        return buf
+
+    def comm_init(self, rank, world_size, unique_id):
+        uid = np.ascontiguousarray(np.asarray(unique_id, np.uint8))
+        _lib.check(self._lib.omc_comm_init(self._h, int(rank), int(world_size), _lib.ptr(uid)))
+        self.rank, self.world_size = int(rank), int(world_size)
+
+    def allreduce_bounds(self, upper_bound, lower_bound):
+        """MIN over ranks of {incumbent UB, smallest open LB}; returns (ub, lb, owner rank of the UB)."""
+        ub = np.array([upper_bound], np.float64); lb = np.array([lower_bound], np.float64); ow = np.zeros(1, np.int32)
+        _lib.check(self._lib.omc_allreduce_bounds(self._h, _lib.ptr(ub), _lib.ptr(lb), _lib.ptr(ow)))
+        return float(ub[0]), float(lb[0]), int(ow[0])
+
+    def bcast_incumbent(self, root, X):
+        Xf = np.asfortranarray(np.asarray(X, np.float64).reshape(self.n, self.m))
+        _lib.check(self._lib.omc_bcast_incumbent(self._h, int(root), _lib.ptr(Xf)))
+        return Xf
+
     # ---- separation / feasibility ----------------------------------------------------------------------
     def breakpoint_vectors(self, Ys, Us, disjunctive_cuts_breakpoints="smallest_1_eigvec"):
         if disjunctive_cuts_breakpoints not in BREAKPOINTS:
@@ -195,8 +219,12 @@ class Engine:
         _lib.check(self._lib.omc_altmin_batch(self._h, B, CUT_TYPES[disjunctive_cuts_type], int(reference_quirk_q1), _lib.ptr(L),
                                               _lib.ptr(cx), _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(U0), float(eps), int(max_iters),
                                               float(time_limit), _lib.ptr(U), _lib.ptr(V), _lib.ptr(cv), _lib.ptr(ni), _lib.ptr(obj), _lib.ptr(tm)))
+        mo = np.zeros(B)
+        _lib.check(self._lib.omc_altmin_master_objectives(self._h, B, _lib.ptr(mo)))
+        # master_objective = evaluate_objective(U V) (OMC.jl:920-927), evaluated on the device from the factors
         return [dict(converged=bool(cv[b]), U=U[b].reshape((n, k), order="F"), V=V[b].reshape((k, m), order="F"),
-                     solve_time=float(tm[b]), n_iters=int(ni[b]), max_iters=max_iters, objectives=list(obj[b, :ni[b]])) for b in range(B)]
+                     solve_time=float(tm[b]), n_iters=int(ni[b]), max_iters=max_iters, objectives=list(obj[b, :ni[b] - (0 if cv[b] or ni[b] == 0 or not np.isnan(obj[b, ni[b] - 1]) else 1)]),
+                     master_objective=float(mo[b])) for b in range(B)]
 
     # ---- objective -------------------------------------------------------------------------------------
     # ---- Shor minors (OMC.jl:2545-2640) ------------------------------------------------------------------------

@@ -85,6 +85,83 @@ def allreduce_bounds(upper_bound, lower_bound, group=None):
     return float(t[0]), float(t[1])
 
 
+class Comm:
+    """The exchanges of node-parallel B&B, one process per GPU.  Per round: the per-node records every rank needs to
+    grow the same tree (status, objective, bound, lambda_min, breakpoint vector, U: ~8 n (k + 1) bytes per node -- never X or Y),
+    one MIN all-reduce of {incumbent UB, stop flag} and, only when the incumbent improved, a broadcast of X from its owner.
+    The bound all-reduce and the X broadcast go through the engine's RCCL communicator (C ABI: omc_allreduce_bounds /
+    omc_bcast_incumbent) when it has been initialised, otherwise through torch.distributed (gloo in the CPU tests)."""
+
+    def __init__(self, rank=0, world_size=1, engine=None, group=None):
+        self.rank, self.world, self.group = int(rank), int(world_size), group
+        self.engine = engine if (engine is not None and getattr(engine, "world_size", 1) == self.world and self.world > 1) else None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group (rendezvous + record exchange)")
+            self.dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+    def allgather_rows(self, rows, width):
+        """rows: (cnt, width) float64 of this rank; returns the rows of all ranks in rank order."""
+        rows = np.asarray(rows, dtype=np.float64).reshape(-1, width)
+        if self.world == 1:
+            return rows
+        import torch
+        import torch.distributed as dist
+        cnt = torch.tensor([rows.shape[0]], dtype=torch.int64, device=self.dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt, group=self.group)
+        cmax = int(max(int(c[0]) for c in cnts))
+        pad = torch.zeros((max(cmax, 1), width), dtype=torch.float64, device=self.dev)
+        if rows.shape[0]:
+            pad[: rows.shape[0]] = torch.from_numpy(np.ascontiguousarray(rows)).to(self.dev)
+        parts = [torch.zeros_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        return np.concatenate([p[: int(c[0])].cpu().numpy() for p, c in zip(parts, cnts)], axis=0)
+
+    def min_bounds(self, ub, lb):
+        """MIN over ranks of (ub, lb) and the smallest rank that holds the minimal ub."""
+        if self.world == 1:
+            return float(ub), float(lb), 0
+        if self.engine is not None:
+            return self.engine.allreduce_bounds(ub, lb)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(ub), float(lb)], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        o = torch.tensor([float(self.rank) if float(ub) == float(t[0]) else float(self.world)], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(o, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t[0]), float(t[1]), int(o[0])
+
+    def bcast_matrix(self, X, root):
+        if self.world == 1:
+            return X
+        if self.engine is not None:
+            return np.array(self.engine.bcast_incumbent(root, X))
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(self.dev)
+        dist.broadcast(t, src=root, group=self.group)
+        return t.cpu().numpy()
+
+    def any_flag(self, flag):
+        """True on every rank when it is true on one (loop termination must be a collective decision)."""
+        if self.world == 1:
+            return bool(flag)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t[0] > 0)
+
+
+def rank_k_projection(X, k):
+    """X_k = U_k U_k' X with U_k = svd(X).U[:, 1:k] (OMC.jl:921): a matrix of rank <= k, so evaluate_objective(X_k) is a valid
+    upper bound of the master problem whatever the relaxation's tolerances were."""
+    Uf = np.linalg.svd(X, full_matrices=False)[0][:, :k]
+    return Uf @ (Uf.T @ X), Uf
+
+
 # ----------------------------------------------------------------------------------------------------------
 # Driver counterpart: matrix_completion_branchandbound (OMC.jl:140-1146) with the node evaluation on the GPU.
 # ----------------------------------------------------------------------------------------------------------
@@ -105,8 +182,10 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     is the certified dual bound (use_certified_bound) instead of the primal value of an eps-optimal point (quirk Q2);
     (3) the queue is a lazy-deletion heap instead of a rebuild per iteration (OMC.jl:1220-1244), same semantics:
     key = parent objective, ties by node id; (4) numpy's RNG replaces Julia's for the altmin coin flips (OMC.jl:867).
-    With world_size > 1 every rank runs the same host logic, relaxes its round-robin shard and the results are
-    all-gathered (independent nodes; bounds are reduced implicitly because every rank sees every result).
+    With world_size > 1 every rank runs the same host logic on the same tree, relaxes its round-robin shard of the popped nodes
+    and the ranks exchange (class Comm) the small per-node records, a MIN all-reduce of the incumbent and -- only when it improved --
+    the incumbent X from its owner; leaving the loop is decided collectively.  (5) A master-feasible node updates the incumbent with
+    evaluate_objective of the rank-k projection of its X, a certified value, instead of the relaxation objective (OMC.jl:818-828).
     Returns (solution, instance) dicts with the reference's key names where they apply (OMC.jl:604-621, 391-454)."""
     import heapq
     import time
@@ -139,9 +218,8 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
         sc = float(np.abs(U0).max())
         starts = [U0] + [U0 + sc * rng.standard_normal((n, k)) for _ in range(max(int(altmin_root_n_iters), 1) - 1)]
         ams = engine.alternating_minimization(starts, [[] for _ in starts], disjunctive_cuts_type)
-        Xs = [a["U"] @ a["V"] for a in ams]
-        objs = np.atleast_1d(engine.evaluate_objective(np.stack(Xs)))
-        X0 = Xs[int(np.argmin(objs))]
+        best = min(ams, key=lambda a: a["master_objective"])          # evaluate_objective(U V) from the factors, on the device
+        X0 = best["U"] @ best["V"]
     else:
         X0 = U0 @ (U0.T @ A0)
     Us, _, _ = np.linalg.svd(X0, full_matrices=False)
@@ -198,7 +276,14 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                 out.append(nid)
         return out
 
-    while now_gap > gap and not (use_max_steps and counters["nodes_total"] >= max_steps) and time.time() - start <= time_limit and nodes:
+    comm = Comm(rank, world_size, engine)
+    REC = 6 + n + n * k              # record every rank needs per relaxed node: id, status, objective, bound, lambda_min[2], x, U
+
+    def keep_going():
+        stop = not (now_gap > gap and not (use_max_steps and counters["nodes_total"] >= max_steps) and time.time() - start <= time_limit and nodes)
+        return not comm.any_flag(stop)           # the clocks of the ranks differ: leaving the loop is a collective decision
+
+    while keep_going():
         ids = pop_ids(batch)
         if not ids:
             break
@@ -212,68 +297,78 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                 todo.append((nid, nd))
         if todo:
             t0 = time.time()
-            mine = todo[rank::world_size] if world_size > 1 else todo
+            mine = todo[rank::world_size] if world_size > 1 else todo                        # round-robin in queue order
             need = [(nid, nd) for nid, nd in mine if nid not in precomputed]
             fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=P,
                                                             want_X=True) if need else []
             fresh = {nid: r for (nid, _), r in zip(need, fresh)}
-            res_mine = [precomputed.pop(nid) if nid in precomputed else fresh[nid] for nid, _ in mine]
-            if world_size > 1:
-                import torch.distributed as dist
-                gathered = [None] * world_size
-                dist.all_gather_object(gathered, [(nid, r) for (nid, _), r in zip(mine, res_mine)])
-                bynid = {nid: r for part in gathered for nid, r in part}
-                results = [bynid[nid] for nid, _ in todo]
-            else:
-                results = res_mine
+            local = {nid: (precomputed.pop(nid) if nid in precomputed else fresh[nid]) for nid, _ in mine}
+            # ---- exchange of the small per-node records (no X, no Y) ------------------------------------------------
+            rows = np.zeros((len(mine), REC))
+            for q, (nid, _) in enumerate(mine):
+                r = local[nid]
+                rows[q, :6] = (nid, r["status_code"], r["objective"], r["dual_bound"], r["lambda_min"][0], r["lambda_min"][1])
+                rows[q, 6:6 + n] = r["breakpoint_vec"]; rows[q, 6 + n:] = np.asarray(r["U"]).ravel(order="F")
+            allrows = comm.allgather_rows(rows, REC)
+            rec = {int(row[0]): row for row in allrows}
             t_relax += time.time() - t0
-            split = []
-            for (nid, nd), r in zip(todo, results):
-                if not r["feasible"]:                                                        # OMC.jl:777-779
+            split = []; cand = []            # cand: (ub candidate, X) found by THIS rank in this round
+            for nid, nd in todo:
+                row = rec[nid]
+                status, objective, bound_cert = int(row[1]), float(row[2]), float(row[3])
+                if status == 3:                                                              # OMC.jl:777-779
                     counters["nodes_relax_infeasible"] += 1
                     continue
                 counters["nodes_relax_feasible"] += 1                                       # OMC.jl:786
-                bound = r["dual_bound"] if use_certified_bound else r["objective"]
+                bound = bound_cert if use_certified_bound else objective
                 nd["LB"] = bound
                 if nid == 1:
                     lb = bound                                                              # OMC.jl:793-795
                 if bound > ub:                                                               # OMC.jl:797-800
                     counters["nodes_relax_feasible_pruned"] += 1
                     continue
-                if r["status_code"] == 0 and r["lambda_min"][0] >= -1e-6:                    # OMC.jl:807-837
+                if status == 0 and row[4] >= -1e-6:                                          # OMC.jl:807-837
                     counters["nodes_master_feasible"] += 1
-                    if r["objective"] < ub:
-                        counters["nodes_master_feasible_improvement"] += 1
-                        ub = r["objective"]
-                        solution.update(objective=ub, X=r["X"], U=r["U"], Y=r["Y"], objective_time_found=time.time() - start)
+                    if nid in local:
+                        # the reference takes the relaxation value as the incumbent (OMC.jl:818-828); a first-order solve certifies that
+                        # value only to eps_gap, so the incumbent is the master objective of the rank-k projection of X instead
+                        Xk, _ = rank_k_projection(local[nid]["X"], k)
+                        cand.append((float(engine.evaluate_objective(Xk)), Xk, "master"))
                     continue
-                split.append((nid, nd, r))
-            # altmin at split nodes w.p. p(depth)  (OMC.jl:856-949)
+                split.append((nid, nd, row))
+            # altmin at split nodes w.p. p(depth)  (OMC.jl:856-949): every rank draws the same coins, runs its own share
             if altmin_flag and split:
                 chosen = []
-                for nid, nd, r in split:
+                for nid, nd, row in split:
                     p = min_altmin_probability if nd["depth"] > altmin_decay_depth else max_altmin_probability / (altmin_probability_decay_rate ** nd["depth"])
                     if rng.random() < p:
-                        chosen.append((nid, nd, r))
+                        chosen.append((nid, nd))
+                counters["nodes_relax_feasible_split_altmin"] += len(chosen)
+                chosen = [(nid, nd) for nid, nd in chosen if nid in local]
                 if chosen:
                     t0 = time.time()
-                    Ur = engine.round_Y([r["Y"] for _, _, r in chosen])                      # OMC.jl:873
-                    ams = engine.alternating_minimization(Ur, [nd["cuts"] for _, nd, _ in chosen], disjunctive_cuts_type)
-                    counters["nodes_relax_feasible_split_altmin"] += len(chosen)
-                    conv = [(a["U"] @ a["V"]) for a in ams if a["converged"]]               # OMC.jl:919-920
+                    Ur = engine.round_Y([local[nid]["Y"] for nid, _ in chosen])              # OMC.jl:873
+                    ams = engine.alternating_minimization(Ur, [nd["cuts"] for _, nd in chosen], disjunctive_cuts_type)
+                    # master objective of U V from the factors, on the device (OMC.jl:919-927): X is formed for the best one only
+                    conv = [a for a in ams if a["converged"]]
                     if conv:
-                        objs = engine.evaluate_objective(np.stack(conv))                     # OMC.jl:925-927
-                        j = int(np.argmin(objs))
-                        for o in objs:
-                            if o < ub:
-                                counters["nodes_relax_feasible_split_altmin_improvement"] += 1
-                        if objs[j] < ub:
-                            ub = float(objs[j]); Xl = conv[j]
-                            Ul = np.linalg.svd(Xl, full_matrices=False)[0][:, :k]            # OMC.jl:921
-                            solution.update(objective=ub, X=Xl, U=Ul, Y=Ul @ Ul.T, objective_time_found=time.time() - start)
+                        j = int(np.argmin([a["master_objective"] for a in conv]))
+                        cand.append((conv[j]["master_objective"], conv[j]["U"] @ conv[j]["V"], "altmin"))
                     t_altmin += time.time() - t0
-            for nid, nd, r in split:                                                         # OMC.jl:951-989
+            # ---- incumbent: 16-byte MIN all-reduce; X travels only when the incumbent improved ---------------------------
+            my_ub = min([c[0] for c in cand], default=math.inf)
+            src = min(cand, key=lambda c: c[0])[2] if cand else "altmin"
+            g_ub, g_src, owner = comm.min_bounds(my_ub, 0.0 if src == "master" else 1.0)     # second slot: which kind of node found it (ties: master)
+            if g_ub < ub:
+                Xl = min(cand, key=lambda c: c[0])[1] if (cand and comm.rank == owner) else np.zeros((n, m))
+                Xl = comm.bcast_matrix(Xl, owner)
+                ub = g_ub
+                Ul = np.linalg.svd(Xl, full_matrices=False)[0][:, :k]                        # OMC.jl:921
+                solution.update(objective=ub, X=Xl, U=Ul, Y=Ul @ Ul.T, objective_time_found=time.time() - start)
+                counters["nodes_master_feasible_improvement" if g_src == 0.0 else "nodes_relax_feasible_split_altmin_improvement"] += 1
+            for nid, nd, row in split:                                                       # OMC.jl:951-989
                 counters["nodes_relax_feasible_split"] += 1
+                r = dict(breakpoint_vec=row[6:6 + n].copy(), U=row[6 + n:].reshape((n, k), order="F").copy())
                 kids = make_children(nd["cuts"], r, disjunctive_cuts_type, k)
                 for cuts in kids:
                     counters["nodes_total"] += 1

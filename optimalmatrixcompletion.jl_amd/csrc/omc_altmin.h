@@ -16,6 +16,7 @@ struct AltminWS {
   double *U, *V;           // B*n, B*m
   double* objectives;      // B*max_iters
   int *converged, *n_iters;
+  double* mobj;            // B: master objective (OMC.jl:2352-2358) of X = U V, evaluated on the device from the factors
   double* G;               // B*Rmax*Rmax scratch
 };
 

@@ -165,6 +165,17 @@ __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
   for (int i = tid; i < n; i += T) w.U[(size_t)b * n + i] = u[i];
   for (int j = tid; j < m; j += T) w.V[(size_t)b * m + j] = v[j];
   if (tid == 0) { w.converged[b] = failed ? 0 : converged; w.n_iters[b] = counter; }
+  {   // evaluate_objective(U V) from the factors (OMC.jl:920, 925-927): 1/2 sum_Omega (u_i v_j - A_ij)^2 + ||u||^2 ||v||^2 / (2 gamma)
+    __syncthreads();
+    double fit = 0.0, uu2 = 0.0, vv2 = 0.0;
+    for (int i = tid; i < n; i += T) {
+      const double ui = u[i]; uu2 += ui * ui;
+      for (int p = w.row_ptr[i]; p < w.row_ptr[i + 1]; ++p) { const double d = ui * v[w.row_idx[p]] - w.row_val[p]; fit += d * d; }
+    }
+    for (int j = tid; j < m; j += T) vv2 += v[j] * v[j];
+    fit = block_sum(fit, red); uu2 = block_sum(uu2, red); vv2 = block_sum(vv2, red);
+    if (tid == 0) w.mobj[b] = 0.5 * fit + uu2 * vv2 / (2.0 * w.gamma);
+  }
 }
 
 
@@ -525,6 +536,29 @@ __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
   for (int e = tid; e < n * k; e += T) { const int i = e % n, a = e / n; w.U[(size_t)b * n * k + e] = u[i * k + a]; }
   for (int e = tid; e < k * m; e += T) w.V[(size_t)b * k * m + e] = v[e];      // k x m column-major = v[j*k + a]
   if (tid == 0) { w.converged[b] = failed ? 0 : converged; w.n_iters[b] = counter; }
+  {   // evaluate_objective(U V) from the factors: masked fit over the CSR rows + tr((U'U)(V V')) / (2 gamma)
+    __syncthreads();
+    double fit = 0.0;
+    for (int i = tid; i < n; i += T) {
+      for (int p = w.row_ptr[i]; p < w.row_ptr[i + 1]; ++p) {
+        const int j = w.row_idx[p];
+        double x = 0.0;
+        for (int a = 0; a < k; ++a) x += u[i * k + a] * v[j * k + a];
+        const double d = x - w.row_val[p]; fit += d * d;
+      }
+    }
+    fit = block_sum(fit, red);
+    double reg = 0.0;
+    for (int a = 0; a < k; ++a)
+      for (int c2 = 0; c2 < k; ++c2) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = tid; i < n; i += T) s1 += u[i * k + a] * u[i * k + c2];
+        for (int j = tid; j < m; j += T) s2 += v[j * k + a] * v[j * k + c2];
+        s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+        reg += s1 * s2;
+      }
+    if (tid == 0) w.mobj[b] = 0.5 * fit + reg / (2.0 * w.gamma);
+  }
 }
 
 extern "C" void omc_launch_altmin_k(const void* ws, size_t lds_bytes, hipStream_t s) {

@@ -22,6 +22,8 @@
 #include "omc_device.h"
 #include "omc_altmin.h"
 #include "omc_shor.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is loaded with dlopen on first use, so that libomc_hip.so has no hard dependency on it
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -76,6 +78,7 @@ struct omc_instance {
   bool staged = false;
   int cone_use_lds = 0, glob_use_lds = 0, small_use_lds = 0; size_t cone_lds = 0, glob_lds = 0, small_lds = 0;
   double last_solve_seconds = 0; long long total_sweeps = 0; int last_iters_total = 0;
+  void* comm = nullptr; int comm_rank = 0, comm_world = 1; DevBuf bcomm, amobj; int amobj_B = 0;
   std::vector<double> rho_scale_per_node; DevBuf brho, brhon, blamD, bslotint, boY, boU, boal, bobx, boscal, boint;
   int Btot = 0;
   // Shor minors (a10 / a11): row bitsets and per-pair popcounts, built at the first call
@@ -190,6 +193,8 @@ int omc_instance_create_bits(int n, int m, int k, const double* A, const uint64_
 void omc_instance_destroy(omc_instance* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  (void)omc_comm_destroy(h);
+  h->bcomm.release(); h->amobj.release();
   DevBuf* all[] = {&h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
@@ -557,7 +562,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       }
       h->ws_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;   // WS_JROWS
       // subspace tracking needs the warm-started kernel as its seed / fall-back and at least 3 x 16 rows
-      w.sub_enable = (h->ws_lpp && n >= 48 && w.np16 <= 192 && omc_cone_sub_lds(w.np16) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE")) ? 1 : 0;
+      w.sub_enable = (h->ws_lpp && n >= 48 && omc_cone_sub_lds(w.np16) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE")) ? 1 : 0;
     }
     h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8 + (size_t)h->nnz * 4 + 16;   // n*m >= n*n: the region also stages Lambda
     h->glob_use_lds = h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS;   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
@@ -934,6 +939,8 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   if ((rc_ = h->aV.ensure(8 * sB * m * k))) return rc_;
   if ((rc_ = h->aobj.ensure(8 * sB * max_iters))) return rc_;
   if ((rc_ = h->aint.ensure(4 * sB * 2))) return rc_;
+  if ((rc_ = h->amobj.ensure(8 * sB))) return rc_;
+  h->amobj_B = B;
   if ((rc_ = h->aG.ensure(8 * sB * Rmax * Rmax))) return rc_;
   AltminWS w{};
   w.B = B; w.n = n; w.m = m; w.k = k; w.Rmax = Rmax; w.Lmax = Lmax; w.max_iters = max_iters;
@@ -943,7 +950,7 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   w.R = h->aR.as<int>(); w.rkind = h->arkind.as<int>(); w.rcut = h->arcut.as<int>(); w.rbi = h->arbi.as<int>(); w.rbj = h->arbj.as<int>();
   w.rcoef = h->arcoef.as<double>(); w.rrhs = h->arrhs.as<double>(); w.cutx = h->acutx.as<double>();
   w.U0 = h->aU0.as<double>(); w.U = h->aU.as<double>(); w.V = h->aV.as<double>(); w.objectives = h->aobj.as<double>();
-  w.converged = h->aint.as<int>(); w.n_iters = h->aint.as<int>() + B; w.G = h->aG.as<double>();
+  w.converged = h->aint.as<int>(); w.n_iters = h->aint.as<int>() + B; w.G = h->aG.as<double>(); w.mobj = h->amobj.as<double>();
   const size_t lds = (k == 1) ? ((size_t)4 * n + m + 2 * Rmax + 8) * 8
                               : ((size_t)4 * n * k + (size_t)2 * n * k * k + (size_t)k * m + 2 * Rmax + 8) * 8;
   if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS - 8 * 1024 : (size_t)128 * 1024)) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: n, m too large for the LDS-resident kernel of this round");
@@ -957,6 +964,14 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   HIPCHK(hipGetLastError());
   const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (solve_time) for (int b = 0; b < B; ++b) solve_time[b] = el;
+  return 0;
+}
+
+int omc_altmin_master_objectives(omc_instance* h, int B, double* objective) {
+  if (!h || !objective) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (B <= 0 || B != h->amobj_B) return fail(OMC_ERR_ARGUMENT, "B does not match the last omc_altmin_batch call");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(objective, h->amobj.p, 8 * (size_t)B, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1198,6 +1213,116 @@ int omc_last_solver_info(omc_instance* h, double* info) {
   if (!h || !info) return fail(OMC_ERR_ARGUMENT, "NULL argument");
   info[0] = h->last_solve_seconds; info[1] = (double)h->total_sweeps; info[2] = h->ws.rho; info[3] = (double)h->ws.rmax;
   info[4] = (double)h->cone_use_lds; info[5] = (double)h->glob_use_lds; info[6] = (double)h->small_use_lds; info[7] = (double)h->ws.Rmax;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RCCL communicator behind the C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+  if (!lib) return fail(OMC_ERR_COMM, std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"));
+  Rccl r; r.lib = lib;
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
+  r.Broadcast = (decltype(r.Broadcast))dlsym(lib, "ncclBroadcast");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.Broadcast || !r.CommDestroy) return fail(OMC_ERR_COMM, "librccl lacks an expected symbol");
+  g_rccl = r;
+  return 0;
+}
+int rccl_fail(ncclResult_t e, const char* what) {
+  return fail(OMC_ERR_COMM, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "RCCL error"));
+}
+}  // namespace
+
+int omc_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(OMC_ERR_ARGUMENT, "id_out is NULL");
+  int rc = rccl_load(); if (rc) return rc;
+  ncclUniqueId id;
+  ncclResult_t e = g_rccl.GetUniqueId(&id);
+  if (e != ncclSuccess) return rccl_fail(e, "ncclGetUniqueId");
+  static_assert(sizeof(ncclUniqueId) == OMC_COMM_ID_BYTES, "unique id size");
+  memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+int omc_comm_init(omc_instance* h, int rank, int world_size, const void* id) {
+  if (!h || !id) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail(OMC_ERR_ARGUMENT, "rank / world_size out of range");
+  if (h->comm) return fail(OMC_ERR_ARGUMENT, "communicator already initialised");
+  int rc = rccl_load(); if (rc) return rc;
+  HIPCHK(hipSetDevice(h->device));
+  ncclUniqueId uid; memcpy(&uid, id, sizeof(uid));
+  ncclComm_t c = nullptr;
+  ncclResult_t e = g_rccl.CommInitRank(&c, world_size, uid, rank);
+  if (e != ncclSuccess) return rccl_fail(e, "ncclCommInitRank");
+  h->comm = (void*)c; h->comm_rank = rank; h->comm_world = world_size;
+  if ((rc = h->bcomm.ensure(64))) return rc;
+  return 0;
+}
+
+int omc_allreduce_bounds(omc_instance* h, double* ub, double* lb, int* owner) {
+  if (!h || !ub || !lb) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (!h->comm) return fail(OMC_ERR_COMM, "omc_comm_init has not been called on this handle");
+  HIPCHK(hipSetDevice(h->device));
+  double* d = h->bcomm.as<double>();
+  const double mine = *ub;
+  double v[2] = {*ub, *lb};
+  HIPCHK(hipMemcpyAsync(d, v, 16, hipMemcpyHostToDevice, h->stream));
+  ncclResult_t e = g_rccl.AllReduce(d, d, 2, ncclDouble, ncclMin, (ncclComm_t)h->comm, h->stream);
+  if (e != ncclSuccess) return rccl_fail(e, "ncclAllReduce(min, fp64[2])");
+  HIPCHK(hipMemcpyAsync(v, d, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *ub = v[0]; *lb = v[1];
+  if (owner) {   // second 8-byte MIN: the smallest rank that holds the minimum (ties are common: every rank starts from the same root bound)
+    double r = (mine == v[0]) ? (double)h->comm_rank : (double)h->comm_world;
+    HIPCHK(hipMemcpyAsync(d + 2, &r, 8, hipMemcpyHostToDevice, h->stream));
+    e = g_rccl.AllReduce(d + 2, d + 2, 1, ncclDouble, ncclMin, (ncclComm_t)h->comm, h->stream);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclAllReduce(min, owner)");
+    HIPCHK(hipMemcpyAsync(&r, d + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *owner = (int)r;
+  }
+  return 0;
+}
+
+int omc_bcast_incumbent(omc_instance* h, int root, double* X) {
+  if (!h || !X) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (!h->comm) return fail(OMC_ERR_COMM, "omc_comm_init has not been called on this handle");
+  if (root < 0 || root >= h->comm_world) return fail(OMC_ERR_ARGUMENT, "root out of range");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t cnt = (size_t)h->n * h->m;
+  int rc = h->bXin.ensure(8 * cnt + 64); if (rc) return rc;
+  double* d = h->bXin.as<double>();
+  if (h->comm_rank == root) HIPCHK(hipMemcpyAsync(d, X, 8 * cnt, hipMemcpyHostToDevice, h->stream));
+  ncclResult_t e = g_rccl.Broadcast(d, d, cnt, ncclDouble, root, (ncclComm_t)h->comm, h->stream);
+  if (e != ncclSuccess) return rccl_fail(e, "ncclBroadcast(X)");
+  if (h->comm_rank != root) HIPCHK(hipMemcpyAsync(X, d, 8 * cnt, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int omc_comm_destroy(omc_instance* h) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)h->comm);
+  h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
   return 0;
 }
 

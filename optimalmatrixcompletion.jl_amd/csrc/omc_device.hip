@@ -1162,35 +1162,39 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   // Z (+ s X) = M X for the row tiles of this wave (up to three, computed together: independent accumulators and twelve loads in
   // flight per lane); operands: M from L2 (symmetric: column k of M is row k), X from LDS
   auto mul_MX = [&](double shift) {
-    const int t0 = wv, t1 = (wv + 4 < nt) ? wv + 4 : wv, t2 = (wv + 8 < nt) ? wv + 8 : wv;     // invalid tiles alias tile wv (results dropped)
-    const bool v1 = wv + 4 < nt, v2 = wv + 8 < nt;
-    double4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0;
-    const double* M0 = Mb + (t0 << 4) + li;
-    const double* M1 = Mb + (t1 << 4) + li;
-    const double* M2 = Mb + (t2 << 4) + li;
-    const double* Xb = Xa + (size_t)li * LD;
-    double a0[4], a1[4], a2[4];
+    for (int tb = 0; tb < nt; tb += 12) {      // 12 row tiles per pass (NP <= 192: one pass)
+      const int b0 = tb + wv;
+      if (b0 >= nt) break;
+      const int t0 = b0, t1 = (b0 + 4 < nt) ? b0 + 4 : b0, t2 = (b0 + 8 < nt) ? b0 + 8 : b0;     // invalid tiles alias tile t0 (results dropped)
+      const bool v1 = b0 + 4 < nt, v2 = b0 + 8 < nt;
+      double4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0;
+      const double* M0 = Mb + (t0 << 4) + li;
+      const double* M1 = Mb + (t1 << 4) + li;
+      const double* M2 = Mb + (t2 << 4) + li;
+      const double* Xb = Xa + (size_t)li * LD;
+      double a0[4], a1[4], a2[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const size_t o = (size_t)(4 * u + lk) * NP; a0[u] = M0[o]; a1[u] = M1[o]; a2[u] = M2[o]; }
-    for (int k0 = 0; k0 < NP; k0 += 16) {
+      for (int u = 0; u < 4; ++u) { const size_t o = (size_t)(4 * u + lk) * NP; a0[u] = M0[o]; a1[u] = M1[o]; a2[u] = M2[o]; }
+      for (int k0 = 0; k0 < NP; k0 += 16) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double x0 = a0[u], x1 = a1[u], x2 = a2[u], bv = Xb[k0 + 4 * u + lk];
-        int kn = k0 + 16 + 4 * u + lk;
-        kn = (kn < NP) ? kn : kn - NP;               // wrapped prefetch of the last chunk is never used
-        const size_t o = (size_t)kn * NP;
-        a0[u] = M0[o]; a1[u] = M1[o]; a2[u] = M2[o];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, bv, acc1, 0, 0, 0);
-        if (nt > 8) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, bv, acc2, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+          const double x0 = a0[u], x1 = a1[u], x2 = a2[u], bv = Xb[k0 + 4 * u + lk];
+          int kn = k0 + 16 + 4 * u + lk;
+          kn = (kn < NP) ? kn : kn - NP;               // wrapped prefetch of the last chunk is never used
+          const size_t o = (size_t)kn * NP;
+          a0[u] = M0[o]; a1[u] = M1[o]; a2[u] = M2[o];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, bv, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, bv, acc1, 0, 0, 0);
+          if (nt > 8) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, bv, acc2, 0, 0, 0);
+        }
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t a = (size_t)li * LD + lk + 4 * r;
-      Za[a + (t0 << 4)] = acc0[r] + shift * Xa[a + (t0 << 4)];
-      if (v1) Za[a + (t1 << 4)] = acc1[r] + shift * Xa[a + (t1 << 4)];
-      if (v2) Za[a + (t2 << 4)] = acc2[r] + shift * Xa[a + (t2 << 4)];
+      for (int r = 0; r < 4; ++r) {
+        const size_t a = (size_t)li * LD + lk + 4 * r;
+        Za[a + (t0 << 4)] = acc0[r] + shift * Xa[a + (t0 << 4)];
+        if (v1) Za[a + (t1 << 4)] = acc1[r] + shift * Xa[a + (t1 << 4)];
+        if (v2) Za[a + (t2 << 4)] = acc2[r] + shift * Xa[a + (t2 << 4)];
+      }
     }
   };
   // Hs = P' Q (16 x 16) for two SUBP x LD blocks: the rows are split over the four waves, partial tiles summed in a fixed order
@@ -1286,18 +1290,15 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       __syncthreads();
       SUBSTAMP(4);
       if (s_flag) { fail = 3; break; }
-      {   // X = Y L^-T by MFMA: X[row][j] = sum_q Y[row][q] Linv[j][q]
+      {   // X = Y L^-T by MFMA: X[row][j] = sum_q Y[row][q] Linv[j][q]  (a row tile of X depends on the same rows of Y only)
+        for (int ti = wv; ti < nt; ti += 4) {
+          const int i0 = ti << 4;
+          double4v a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int ti = wv + 4 * q, i0 = ti << 4;
-          if (ti < nt) {
-            double4v a1 = {0.0, 0.0, 0.0, 0.0};
+          for (int u = 0; u < 4; ++u)
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], Hs[li * 17 + 4 * u + lk], a1, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-              a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], Hs[li * 17 + 4 * u + lk], a1, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Xa[(size_t)li * LD + i0 + lk + 4 * r] = a1[r];
-          }
+          for (int r = 0; r < 4; ++r) Xa[(size_t)li * LD + i0 + lk + 4 * r] = a1[r];
         }
       }
       __syncthreads();
@@ -1333,30 +1334,19 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
     SUBSTAMP(7);
     Hs[(tid >> 4) * 17 + (tid & 15)] = Gj[(tid & 15) * 17 + (tid >> 4)] * rsqrt(evj[tid & 15]);    // Wr[k][t] = g_t[k] / nu_t
     __syncthreads();
-    {   // X <- X Wr, Z <- Z Wr (results held in registers until every wave has finished reading; <= 3 row tiles per wave: NP <= 192)
-      double4v ax[3], az[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int ti = wv + 4 * q, i0 = ti << 4;
+    {   // X <- X Wr, Z <- Z Wr, in place: a row tile depends on its own rows only, and a wave reads its tile completely before it writes
+      for (int ti = wv; ti < nt; ti += 4) {
+        const int i0 = ti << 4;
         double4v a1 = {0.0, 0.0, 0.0, 0.0}, a2 = {0.0, 0.0, 0.0, 0.0};
-        if (ti < nt) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double bw = Hs[(4 * u + lk) * 17 + li];
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[(size_t)(4 * u + lk) * LD + i0 + li], bw, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], bw, a2, 0, 0, 0);
-          }
+        for (int u = 0; u < 4; ++u) {
+          const double bw = Hs[(4 * u + lk) * 17 + li];
+          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[(size_t)(4 * u + lk) * LD + i0 + li], bw, a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], bw, a2, 0, 0, 0);
         }
-        ax[q] = a1; az[q] = a2;
-      }
-      __syncthreads();
+        WAVE_SYNC();
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int ti = wv + 4 * q, i0 = ti << 4;
-        if (ti < nt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const size_t a = (size_t)li * LD + i0 + lk + 4 * r; Xa[a] = ax[q][r]; Za[a] = az[q][r]; }
-        }
+        for (int r = 0; r < 4; ++r) { const size_t a = (size_t)li * LD + i0 + lk + 4 * r; Xa[a] = a1[r]; Za[a] = a2[r]; }
       }
       __syncthreads();
     }

@@ -36,6 +36,12 @@ def readme_instance(n, m, seed):
     return rng.standard_normal((n, m)), rng.integers(0, 2, (n, m)).astype(bool)
 
 
+def branching_instance(seed=0, n=100, m=100, noise=0.3, frac=0.1):
+    """A 100 x 100 rank-1 instance whose B&B tree really branches (BASELINE config 2's own tree closes at the root: its relaxation
+    is tight): the reference's generator (utils.jl:98-103) with noise 0.3 instead of 0.01 and 10 % observed instead of 20 %."""
+    return generate_matrix_completion_data(1, n, m, int(round(frac * n * m)), seed, noise=noise)
+
+
 def instance_sha256(A, mask):
     h = hashlib.sha256()
     h.update(np.ascontiguousarray(A, dtype=np.float64).tobytes()); h.update(np.ascontiguousarray(mask, dtype=np.uint8).tobytes())

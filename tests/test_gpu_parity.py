@@ -654,3 +654,75 @@ def test_violated_shor_minors_config5_size(have_gpu, omc):
     st = eng.shor_last_stats()
     assert st["candidates"] > 1_000_000_000
     eng.close()
+
+
+def test_config4_shape_capped_iterations_properties(have_gpu, omc):
+    """BASELINE config 4 shape (500 x 500, rank 2, linear3 + smallest_2_eigvec): the oracle would need hours, so a capped solve is checked
+    by properties -- finite outputs, a valid bound below the primal value of the (nearly feasible) iterate, Y inside the cone to the
+    accuracy the residual reports, and the cone block really running on the tracked subspace (no eigendecomposition after the seed)."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(4, seed=0)
+    eng = omc.Engine(A, mask, gamma, c["k"])
+    P = omc.default_params(rho_scale=4.0, max_iters=100, breakpoints=2)
+    root = eng.matrix_completion_SDP_relaxation([[]], "linear3", params=P, want_X=False)[0]
+    assert_finite(root)
+    assert root["iters"] == 100 and root["feasible"]
+    assert root["dual_bound"] <= root["objective"] * (1 + 1e-3)            # a valid bound under the value of a nearly feasible point
+    w = np.linalg.eigvalsh(root["Y"])
+    assert w[0] >= -1e-3 and w[-1] <= 1 + 1e-3 and np.trace(root["Y"]) <= 2 + 1e-6
+    st = eng.subspace_stats()
+    assert st["calls"] >= 60 and st["fallbacks"] <= 5, st                 # the order-500 projection is done by the 16-vector block
+    x = root["breakpoint_vec"]
+    assert abs(np.linalg.norm(x) - 1.0) < 1e-9                            # smallest_2 mix has unit norm (w1^2 + w2^2 = 1, OMC.jl:2471-2476)
+    # one level of children (16 = 4^2 direction pairs, OMC.jl:2481-2491) is a legal batch at this size
+    kids = omc.pkg.bnb.make_children([], root, "linear3", 2)
+    assert len(kids) == 16
+    out = eng.matrix_completion_SDP_relaxation(kids[:4], "linear3", params=omc.default_params(rho_scale=4.0, max_iters=50, breakpoints=2), want_X=False, want_Y=False)
+    for o in out:
+        assert_finite(o)
+        assert o["status_code"] in (0, 1, 3)
+    eng.close()
+
+
+def test_altmin_config2_size_deep_cut_list(have_gpu, omc, orc):
+    """alternating_minimization at BASELINE config 2 size (100 x 100, rank 1) with a depth-8 cut list (16 bound rows + symmetry row):
+    same iteration count and objectives as the oracle, and the device-side master objective of U V (OMC.jl:920-927) equals
+    evaluate_objective of the product."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(2, seed=1)
+    n, m = A.shape
+    inst = orc.Instance(A, mask, gamma, 1)
+    eng = omc.Engine(A, mask, gamma, 1)
+    rng = np.random.default_rng(4)
+    U0 = orc.svd_rounding(np.where(mask, A, 0.0), 1)
+    cuts = []
+    for l in range(8):
+        x = rng.standard_normal(n); x /= np.linalg.norm(x)
+        vhat = float(U0[:, 0] @ x)
+        cuts.append((x, U0 * (0.8 if l % 2 else 1.2), ["left" if (vhat * (0.8 if l % 2 else 1.2)) > vhat else "right"]))   # every cut keeps U0 feasible
+    got = eng.alternating_minimization([U0, U0 + 0.02 * rng.standard_normal((n, 1))], [cuts, cuts], "linear")
+    for g, u0 in zip(got, [U0, None]):
+        if u0 is None:
+            continue
+        r = orc.alternating_minimization(inst, u0, cuts, "linear")
+        assert g["converged"] == r["converged"] and g["n_iters"] == r["n_iters"]
+        assert np.allclose(g["objectives"], r["objectives"], rtol=1e-9)
+        assert np.allclose(g["U"], r["U"], atol=1e-7)
+    for g in got:
+        X = g["U"] @ g["V"]
+        assert g["master_objective"] == pytest.approx(orc.evaluate_objective(X, A, mask, gamma), rel=1e-12)
+        assert g["master_objective"] == pytest.approx(eng.evaluate_objective(X), rel=1e-12)
+    eng.close()
+
+
+def test_rccl_communicator_single_rank(have_gpu, omc):
+    """omc_comm_init / omc_allreduce_bounds / omc_bcast_incumbent (C ABI over RCCL) with a world of one rank: the
+    collectives run through librccl on the device and return the inputs."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(1, seed=0)
+    eng = omc.Engine(A, mask, gamma, 1)
+    eng.comm_init(0, 1, omc.Engine.comm_unique_id())
+    ub, lb, owner = eng.allreduce_bounds(3.5, -1.25)
+    assert (ub, lb, owner) == (3.5, -1.25, 0)
+    X = np.arange(A.size, dtype=float).reshape(A.shape)
+    assert np.array_equal(eng.bcast_incumbent(0, X), X)
+    with pytest.raises(omc.OmcError):
+        eng.comm_init(0, 1, omc.Engine.comm_unique_id())                  # already initialised
+    eng.close()
