@@ -1,0 +1,36 @@
+"""Summaries of rocprofv3 CSV output for profiles/ (tracked):
+   summarize_prof.py stats <dir> <out.csv>        kernel-trace: calls / total / average / min / max per kernel
+   summarize_prof.py pmc <dir> <out.txt> <title>  counter collection: per-launch averages per kernel and counter"""
+import csv, glob, os, sys
+from collections import defaultdict
+
+def short(name):
+    return name.replace("(OmcWS)", "").replace("(OmcWS, int)", "").replace("void ", "").strip()
+
+mode, d, out = sys.argv[1], sys.argv[2], sys.argv[3]
+if mode == "stats":
+    f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    acc = defaultdict(lambda: [0, 0, 10**18, 0])
+    for r in csv.DictReader(open(f)):
+        t = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a = acc[r["Kernel_Name"]]
+        a[0] += 1; a[1] += t; a[2] = min(a[2], t); a[3] = max(a[3], t)
+    tot = sum(a[1] for a in acc.values())
+    with open(out, "w", newline="") as fo:
+        w = csv.writer(fo, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for k_, a in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k_, a[0], a[1], round(a[1] / a[0], 1), round(100.0 * a[1] / tot, 3), a[2], a[3]])
+            if a[1] > 0.005 * tot: print("%-60s calls %7d avg %9.1f us  %5.1f %%" % (short(k_)[:60], a[0], a[1] / a[0] / 1e3, 100.0 * a[1] / tot))
+else:
+    title = sys.argv[4] if len(sys.argv) > 4 else ""
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0])); grid = {}
+    for r in csv.DictReader(open(f)):
+        a = acc[r["Kernel_Name"]][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"]); grid[r["Kernel_Name"]] = r["Grid_Size"]
+    with open(out, "w") as fo:
+        fo.write(title + "\n")
+        for k_, cs in sorted(acc.items()):
+            if k_.startswith("__amd") or not any(v[1] for v in cs.values()): continue
+            n_ = max(v[0] for v in cs.values())
+            line = "%s launches=%d last_grid=%s " % (short(k_), n_, grid[k_]) + " ".join("%s=%.4g" % (c, v[1] / v[0]) for c, v in sorted(cs.items()))
+            fo.write(line + "\n"); print(line)
