@@ -88,6 +88,9 @@ typedef struct omc_relax_params {
   double aa_safeguard; /*   the point is kept when the next fixed-point residual <= this x the last  (1.0)   */
   int first_wins;      /* 1: the batch ends at the first check at which some node is OPTIMAL; the others are
                           returned as they stand (SLOW_PROGRESS, values available).  Penalty autotune.  (0)     */
+  int early_stop_after;     /* a node whose gap, at the geometric rate it closed over the last checks, needs more than       */
+  double early_stop_factor; /*   early_stop_factor x the checks left before max_iters is returned as OMC_SLOW_PROGRESS at once
+                                 (eight consecutive predictions, from iteration early_stop_after on); 0 = off   (400, 1.5) */
 } omc_relax_params;
 
 void omc_relax_params_default(omc_relax_params* p);

@@ -25,7 +25,8 @@ class RelaxParams(C.Structure):
                 ("rho_scale", C.c_double), ("rho_f_ratio", C.c_double), ("relax", C.c_double), ("time_limit", C.c_double),
                 ("reference_quirk_q1", C.c_int), ("breakpoints", C.c_int), ("stall_checks", C.c_int), ("bump_max", C.c_int), ("bump_ratio", C.c_double),
                 ("bump_factor", C.c_double), ("bump_after", C.c_int), ("bump_window", C.c_int), ("slots", C.c_int),
-                ("accel", C.c_int), ("aa_mem", C.c_int), ("aa_every", C.c_int), ("aa_start", C.c_int), ("aa_reg", C.c_double), ("aa_safeguard", C.c_double), ("first_wins", C.c_int)]
+                ("accel", C.c_int), ("aa_mem", C.c_int), ("aa_every", C.c_int), ("aa_start", C.c_int), ("aa_reg", C.c_double), ("aa_safeguard", C.c_double), ("first_wins", C.c_int),
+                ("early_stop_after", C.c_int), ("early_stop_factor", C.c_double)]
 
 
 class OmcError(RuntimeError):

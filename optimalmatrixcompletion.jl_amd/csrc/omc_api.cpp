@@ -70,6 +70,7 @@ struct omc_instance {
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
   DevBuf bobjcol, baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
+  DevBuf bslotlist, bgap, bvotes;
   DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow, bXs, bsubS, bsubI;
   long long sub_tot[8] = {0};
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
@@ -108,6 +109,7 @@ void omc_relax_params_default(omc_relax_params* p) {
   p->reference_quirk_q1 = 1; p->breakpoints = OMC_SMALLEST_1_EIGVEC; p->stall_checks = 8;
   p->bump_max = 2; p->bump_ratio = 4.0; p->bump_factor = 4.0; p->bump_after = 100; p->bump_window = 4; p->slots = 0;
   p->accel = 0; p->aa_mem = 10; p->aa_every = 10; p->aa_start = 50; p->aa_reg = 1e-10; p->aa_safeguard = 1.0; p->first_wins = 0;
+  p->early_stop_after = 400; p->early_stop_factor = 1.5;
 }
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t s) {
@@ -199,7 +201,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
-                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI,
+                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
@@ -400,6 +402,14 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.rho_b = h->brho.as<double>();
   }
   w.relax = P.relax; w.eps_gap = P.eps_gap; w.eps_feas = P.eps_feas;
+  w.check_every = std::max(1, P.check_every); w.early_stop_after = P.early_stop_after; w.early_stop_factor = (P.first_wins ? 0.0 : P.early_stop_factor);
+  {
+    int r0 = h->bgap.ensure(sizeof(double) * 2 * (size_t)S); if (r0) return r0;
+    r0 = h->bvotes.ensure(sizeof(int) * (size_t)S); if (r0) return r0;
+    r0 = h->bslotlist.ensure(sizeof(int) * (size_t)S); if (r0) return r0;
+    w.gap_prev = h->bgap.as<double>(); w.gap_rate = h->bgap.as<double>() + S; w.slow_votes = h->bvotes.as<int>();
+    w.slot_list = nullptr;      // set on the per-iteration copies only (omc_relax_solve)
+  }
   std::vector<double> wY((size_t)n * n);
   for (size_t e = 0; e < (size_t)n * n; ++e) wY[e] = P.rho_f_ratio * h->Ncnt[e] + 2.0;
   int rc_ = 0;
@@ -648,6 +658,19 @@ int omc_relax_solve(omc_instance* h) {
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
   }
+  // compact list of the slots that hold a node: the per-iteration kernels launch over it (rebuilt after every refill)
+  std::vector<int> alist(S);
+  for (int b = 0; b < S; ++b) alist[b] = b;
+  int nlist = S;
+  const bool use_list = !(getenv("OMC_NO_SLOT_LIST"));
+  auto push_list = [&]() -> int {
+    nlist = 0;
+    for (int b = 0; b < S; ++b) if (node_of[b] >= 0) alist[nlist++] = b;
+    if (nlist) HIPCHK(hipMemcpyAsync(h->bslotlist.p, alist.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+  };
+  { int rc = push_list(); if (rc) return rc; }
   int gb0[2] = {0, 0}, gnB[2] = {S, 0}, gact[2] = {S, 0};
   if (G == 2) { gnB[0] = S / 2; gb0[1] = S / 2; gnB[1] = S - S / 2; gact[0] = gnB[0]; gact[1] = gnB[1]; }
   bool timed_out = false;
@@ -660,6 +683,7 @@ int omc_relax_solve(omc_instance* h) {
     for (int g = 0; g < G; ++g) {
       if (gact[g] == 0) continue;
       OmcWS wg = w; wg.b0 = gb0[g]; wg.nB = gnB[g];
+      if (use_list && G == 1) { wg.slot_list = h->bslotlist.as<int>(); wg.b0 = 0; wg.nB = nlist; }
       hipStream_t sm = multi ? h->gs[g][0] : s, sb = multi ? h->gs[g][1] : s, sc = multi ? h->gs[g][2] : s;
       if (multi) {
         if (wait_main) HIPCHK(hipStreamWaitEvent(sm, h->ev_main, 0));
@@ -742,6 +766,7 @@ int omc_relax_solve(omc_instance* h) {
     }
     nactive = 0; gact[0] = gact[1] = 0;
     for (int b = 0; b < S; ++b) if (node_of[b] >= 0) { ++nactive; ++gact[(G == 2 && b >= gb0[1]) ? 1 : 0]; }
+    if (nfin) { int rc = push_list(); if (rc) return rc; }
     if (timed_out && next < Btot) {
       // nodes that never got a slot: report TIME_LIMIT without values
       std::vector<int> st(Btot - next, OMC_ST_TIME), itz(Btot - next, 0);

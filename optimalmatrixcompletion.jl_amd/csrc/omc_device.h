@@ -31,6 +31,9 @@ struct OmcWS {
   int b0, nB;   // slot range [b0, b0 + nB) handled by a launch of the per-iteration kernels (the slots are split in groups that run on their own streams)
   int B, Btot, n, m, k, nnz, Rmax, Lmax, breakpoints, rmax, stall_checks, np16, max_sweeps, max_iters;
   int *node_of, *init, *fin;   // B
+  const int* slot_list;        // compact list of the slots that hold a node (rebuilt by the host at every check): the per-iteration kernels launch over it
+  int check_every, early_stop_after; double early_stop_factor;   // stop a node as SLOW_PROGRESS once its gap cannot close before max_iters (k_check_final)
+  double *gap_prev, *gap_rate; int* slow_votes;                  // B each
   const double* rho_node;      // Btot: initial penalty of each node
   double *oY, *oU, *oalphaX, *obx, *oobj, *olb, *olmin, *orho; int *ostatus, *oiters;   // per-node outputs
   // parameters

@@ -18,6 +18,9 @@
 
 #include "omc_wave.h"
 
+// slot handled by workgroup / wave group i of a per-iteration launch
+__device__ __forceinline__ int slot_of(const OmcWS& w, int i) { return w.slot_list ? w.slot_list[w.b0 + i] : w.b0 + i; }
+
 // optional phase stamps (diagnostic builds only: -DOMC_STAMPS): block 0 accumulates s_memtime deltas per phase
 #ifdef OMC_STAMPS
 #define STAMP(slot) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { long long t_ = __builtin_amdgcn_s_memtime(); w.stamps[slot] += (double)(t_ - t_prev_); t_prev_ = t_; } } while (0)
@@ -99,7 +102,7 @@ __global__ void k_setup(OmcWS w) {
   if (tid == 0) {
     w.init[b] = 0; w.rho_b[b] = w.rho_node[nb];
     if (w.accel) { w.aa_valid[b] = 0; w.aa_hist[b] = 0; w.aa_head[b] = 0; w.aa_pending[b] = 0; w.aa_nacc[b] = 0; w.aa_nrej[b] = 0; }
-    w.done[b] = 0; w.rowov[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0; w.nbump[b] = 0; w.lastbump[b] = 0; w.bfac[b] = 1.0;
+    w.done[b] = 0; w.rowov[b] = 0; w.gap_prev[b] = 1e300; w.gap_rate[b] = 1.0; w.slow_votes[b] = 0; w.status[b] = OMC_ST_SLOW; w.iters[b] = 0; w.stall[b] = 0; w.nbump[b] = 0; w.lastbump[b] = 0; w.bfac[b] = 1.0;
     w.obj[b] = 1e300; w.objout[b] = 1e300; w.objprev[b] = 1e300; w.lbprev[b] = -1e300; w.lb[b] = -1e300; w.rp[b] = 1e300; w.rd[b] = 1e300;
   }
   // Gram matrix for rho = 1
@@ -416,8 +419,9 @@ __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   extern __shared__ double smem[];
   const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const int gw = blockIdx.x * wpb + wave_in_blk;  // global wave id
-  const int bl = gw / w.m, j = gw - bl * w.m, b = bl + w.b0;
+  const int bl = gw / w.m, j = gw - bl * w.m;
   if (bl >= w.nB) return;
+  const int b = slot_of(w, bl);
   if (w.done[b]) return;
   const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
   if (c == 0) { if (mode == 1 && lane == 0) { w.objcol[(size_t)b * w.m + j] = 0.0; w.c0col[(size_t)b * w.m + j] = 0.0; } return; }
@@ -744,7 +748,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
   __shared__ int s_cnt;
   __shared__ int s_nsel;
   __shared__ double s_base;
-  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
+  const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] && mode != CONE_SEP && mode != CONE_TOPK) return;
   if ((mode == CONE_SEP || mode == CONE_TOPK) && !w.fin[b]) return;
   const int n = w.n, k = w.k;
@@ -876,7 +880,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   extern __shared__ double smem[];
   __shared__ int s_nsel, s_nkeep, s_top[SUBP];
   __shared__ double s_base;
-  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
+  const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
   if (!w.ws_mode && w.sub_enable && w.cone_done[b]) return;      // k_cone_sub has already written W1 for this iteration
   const int n = w.n, N = n, NP = w.np16;
@@ -1134,7 +1138,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   extern __shared__ double smem[];
   __shared__ int s_flag, s_nsel;
   __shared__ double s_shift;
-  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
+  const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] || !w.sub_on[b]) return;
   if (w.sub_wait[b] > 0) { if (threadIdx.x == 0) w.sub_wait[b] -= 1; return; }     // backing off after a failed call
   const int n = w.n, NP = w.np16, nt = NP >> 4, LD = NP + 2;
@@ -1425,7 +1429,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   __shared__ double red[32];
   __shared__ int s_cnt, s_nsel;
   __shared__ double s_base;
-  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
+  const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] && mode == SMALL_PROJ) return;
   if (mode == SMALL_RECOVER && !w.fin[b]) return;   // recovery runs once, when the slot's node is harvested
   const int nb = w.node_of[b];
@@ -1624,7 +1628,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   __shared__ double s_Gp[NNQP_PMAX * (NNQP_PMAX + 1) / 2];
   __shared__ double s_sv[NNQP_PMAX], s_tmp[NNQP_PMAX];
   __shared__ int s_pl[NNQP_PMAX];
-  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
+  const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
   const int nb = w.node_of[b];
   const int n = w.n, k = w.k, m = w.m, rm = w.rmax;
@@ -1942,11 +1946,28 @@ __global__ void k_check_final(OmcWS w, int last) {
   }
   if (last) { w.done[b] = 1; w.status[b] = last; return; }
   if (w.iters[b] >= w.max_iters) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }
+  // early SLOW_PROGRESS: the gap of a crawling node decays geometrically (measured: a constant factor per check).  With q the
+  // exponential average of gap_now / gap_previous, closing the rest takes log(gap / target) / log(1 / q) checks; when that exceeds
+  // early_stop_factor x the checks left before max_iters the node cannot be certified any more -- its values and its (valid) bound
+  // are returned now instead of after the iteration cap.  Eight consecutive such predictions are required.
+  if (w.early_stop_factor > 0.0) {
+    const double target = w.eps_gap * fmax(1.0, fabs(obj));
+    const double gnow = obj - w.lb[b];
+    const double gp = w.gap_prev[b];
+    const double q = (gp < 1e299 && gp > 0.0 && gnow > 0.0) ? 0.5 * w.gap_rate[b] + 0.5 * fmin(gnow / gp, 2.0) : 1.0;
+    w.gap_prev[b] = gnow; w.gap_rate[b] = q;
+    const double left = (double)(w.max_iters - w.iters[b]) / (double)w.check_every;
+    const double need = (q < 1.0) ? log(fmax(gnow, target) / target) / -log(q) : 1e300;
+    const bool hopeless = w.iters[b] >= w.early_stop_after && gnow > target && need > w.early_stop_factor * left;   // an infeasible iterate understates the gap: no feasibility condition
+    w.slow_votes[b] = hopeless ? w.slow_votes[b] + 1 : 0;
+    if (w.slow_votes[b] >= 8) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }
+  }
   // penalty bump: crawling nodes with active cuts show rp >> rd
   w.bfac[b] = 1.0;
   if (w.bump_max > 0 && w.iters[b] >= w.bump_after && w.nbump[b] < w.bump_max && w.iters[b] - w.lastbump[b] >= w.bump_gap &&
       w.rp[b] > w.bump_ratio * w.rd[b]) {
     w.bfac[b] = w.bump_factor; w.rho_b[b] *= w.bump_factor; w.nbump[b] += 1; w.lastbump[b] = w.iters[b];
+    w.slow_votes[b] = 0; w.gap_rate[b] = 1.0;      // a new penalty changes the rate: the early-stop prediction starts over
   }
 }
 
@@ -1990,7 +2011,7 @@ __global__ void __launch_bounds__(512) k_aa(OmcWS w) {
   __shared__ double red[32];
   __shared__ double s_H[AA_MAXMEM * AA_MAXMEM], s_rhs[AA_MAXMEM], s_gam[AA_MAXMEM];
   __shared__ int s_ok;
-  const int b = blockIdx.x + w.b0, tid = threadIdx.x, T = blockDim.x;
+  const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
   const int it = w.iters[b];
   if (it < w.aa_start - 1) return;

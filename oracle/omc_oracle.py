@@ -467,6 +467,9 @@ class RelaxParams:
     aa_start: int = 50           # ... from this iteration on
     aa_reg: float = 1e-10        # Tikhonov weight of the normal equations, relative to the mean diagonal
     aa_safeguard: float = 1.0    # the point is kept when the next fixed-point residual <= this x the last one
+    # early SLOW_PROGRESS (mirrors k_check_final): the gap cannot close before max_iters at the rate of the last checks
+    early_stop_after: int = 400
+    early_stop_factor: float = 1.5   # 0 = off
 
 
 def _prox_columns(inst, Yx, alpha, svals, rho_f):
@@ -661,6 +664,7 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
     it = 0; rx = p.relax
     stall = 0; obj_prev = math.inf; lb_prev = -math.inf
     n_bumps = 0; last_bump = 0
+    gap_prev = 1e300; gap_rate = 1.0; slow_votes = 0
     Q3 = np.zeros((r + k, r + k))
     # Anderson acceleration: state z = (Y, Yp, D1, D3, Vt, D3V, D3T, alpha); ring of (f, g) pairs; see k_aa
     def aa_pack():
@@ -732,6 +736,19 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
             if time.time() - t0 > p.time_limit:
                 status = OMC_TIME_LIMIT
                 break
+            if it >= p.max_iters:
+                break
+            if p.early_stop_factor > 0.0:
+                target = p.eps_gap * max(1.0, abs(obj))
+                gnow = obj - lb
+                q = 0.5 * gap_rate + 0.5 * min(gnow / gap_prev, 2.0) if (gap_prev < 1e299 and gap_prev > 0.0 and gnow > 0.0) else 1.0
+                gap_prev = gnow; gap_rate = q
+                left = (p.max_iters - it) / float(p.check_every)
+                need = math.log(max(gnow, target) / target) / -math.log(q) if q < 1.0 else 1e300
+                hopeless = it >= p.early_stop_after and gnow > target and need > p.early_stop_factor * left
+                slow_votes = slow_votes + 1 if hopeless else 0
+                if slow_votes >= 8:
+                    break                                              # SLOW_PROGRESS now: values and the (valid) bound are returned
             # penalty bump: nodes with active cuts want a larger rho than the root-tuned one.  Signal (measured on config 2):
             # crawling nodes sit at rp/rd = 10..200 at iteration 400, healthy ones at 0.4..4
             if (p.bump and it >= p.bump_after and n_bumps < p.bump_max and it - last_bump >= p.check_every * p.bump_window
@@ -740,6 +757,7 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
                 rho *= fac
                 D1 /= fac; D3 /= fac; D3V /= fac; D3T /= fac
                 n_bumps += 1; last_bump = it
+                slow_votes = 0; gap_rate = 1.0                         # a new penalty changes the rate: the prediction starts over
                 aa_valid = False                                       # the map changed: restart the history
         # ---- Anderson acceleration (mirrors k_aa: runs after the certificate, on the state the next iteration reads) ----
         if p.accel and it >= p.aa_start - 1 and not aa_off:

@@ -248,7 +248,7 @@ def test_objective_functions_and_errors():
 
 
 def test_oracle_anderson_acceleration_converges_crawling_node(orc):
-    """The README fixture's node L = 2 crawls (SLOW_PROGRESS at the cap); with accel = 1 the oracle certifies it in a few
+    """The README fixture's node L = 2 crawls (SLOW_PROGRESS); with accel = 1 the oracle certifies it in a few
     hundred iterations and returns the same optimum value."""
     import os
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_20x24_k1_linear.npz"), allow_pickle=False)
@@ -256,7 +256,7 @@ def test_oracle_anderson_acceleration_converges_crawling_node(orc):
     cuts = [(z["cut_x"][l], z["cut_U"][l], [DN[int(c)] for c in z["cut_dir"][l]]) for l in range(2)]
     inst = orc.Instance(z["A"], z["mask"], 80.0, 1)
     r = orc.sdp_relaxation(inst, cuts, "linear", params=orc.RelaxParams(rho_scale=16.0, accel=1), want_certificate=False)
-    assert int(z["status"][2]) == 1 and int(z["iters"][2]) == 3000          # without acceleration (golden)
+    assert int(z["status"][2]) == 1 and int(z["iters"][2]) >= 1000          # without acceleration (golden): SLOW_PROGRESS, stopped early once hopeless
     assert r["termination_status"] == 0 and r["iters"] <= 500 and r["n_aa"] > 10
     assert r["objective"] == pytest.approx(float(z["objective"][2]), rel=2e-6)
     assert r["objective"] - r["dual_bound"] <= 1e-6 * max(1.0, abs(r["objective"]))
