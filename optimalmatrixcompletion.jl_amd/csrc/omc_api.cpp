@@ -70,7 +70,7 @@ struct omc_instance {
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
   DevBuf bobjcol, baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
-  DevBuf bslotlist, bgap, bvotes;
+  DevBuf bslotlist, bgap, bvotes, blamDX;
   DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow, bXs, bsubS, bsubI;
   long long sub_tot[8] = {0};
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
@@ -201,7 +201,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
-                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes,
+                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes, &h->blamDX,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
@@ -433,6 +433,12 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   ENS(h->blamD, sB * m * n * 8);
   HIPCHK(hipMemsetAsync(h->blamD.p, 0, sB * m * n * 8, h->stream));
   w.lamD = h->blamD.as<double>();
+  w.lamDX = nullptr;
+  if (n > 144 || getenv("OMC_DENSE_CHECK")) {      // large orders: the certificate matrix takes Lambda Lambda' from one MFMA product
+    ENS(h->blamDX, sB * m * n * 8);
+    HIPCHK(hipMemsetAsync(h->blamDX.p, 0, sB * m * n * 8, h->stream));
+    w.lamDX = h->blamDX.as<double>();
+  }
   w.Mbuf = h->bMbuf.as<double>(); w.Vrow = h->bVrow.as<double>();
   {   // tracked subspace of the cone block (k_cone_sub)
     ENS(h->bXs, sB * w.np16 * 16 * 8); ENS(h->bsubS, sB * 17 * 8); ENS(h->bsubI, sB * 12 * sizeof(int));

@@ -50,6 +50,7 @@ struct OmcWS {
   const int* row_ptr;     // n+1: CSR of the observed entries (row -> observed columns)
   const int* row_idx;     // nnz
   double* lamD;           // B*m*n: dense column-major copy of Lambda (zero off the support)
+  double* lamDX;          // same for the exact multipliers of the certificate (k_colprox mode 1); NULL for the small orders that keep the scattered form
   const double* wY1;      // n*n: consensus weight of Y entries for rho = 1: rho_f_ratio*Ncnt + 2
   // per-node state (node stride in comments)
   double *Y, *Yp;         // n*n

@@ -262,8 +262,9 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
     double yr = 0.0, zr = 0.0;
     solve2(yr, zr, false);
     double aa = 0.0, al2 = 0.0;
-    if (regpath) { aa = a_reg * yr; al2 = yr * yr; if (lane < c) alpha[lane] = yr; }
-    else for (int p = lane; p < c; p += WAVE) { aa += va[p] * vy[p]; al2 += vy[p] * vy[p]; alpha[p] = vy[p]; }
+    double* lamX = w.lamDX ? w.lamDX + ((size_t)b * w.m + j) * n : nullptr;
+    if (regpath) { aa = a_reg * yr; al2 = yr * yr; if (lane < c) { alpha[lane] = yr; if (lamX) lamX[idx[lane]] = yr; } }
+    else for (int p = lane; p < c; p += WAVE) { aa += va[p] * vy[p]; al2 += vy[p] * vy[p]; alpha[p] = vy[p]; if (lamX) lamX[idx[p]] = vy[p]; }
     aa = wave_sum(aa); al2 = wave_sum(al2);
     if (lane == 0) { w.objcol[(size_t)b * w.m + j] = 0.5 * aa; w.c0col[(size_t)b * w.m + j] = aa - 0.5 * al2; }   // summed in a fixed order by k_check_build
   }
@@ -409,7 +410,7 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
       return;
     }
     const double yr = wave_ldl_solve_reg(Lm, pinv, c, a_reg, lane);
-    if (lane < c) alpha[lane] = yr;
+    if (lane < c) { alpha[lane] = yr; if (w.lamDX) w.lamDX[((size_t)b * w.m + j) * n + my] = yr; }
     const double aa = wave_sum(a_reg * yr), al2 = wave_sum(yr * yr);
     if (lane == 0) { w.objcol[(size_t)b * w.m + j] = 0.5 * aa; w.c0col[(size_t)b * w.m + j] = aa - 0.5 * al2; }   // summed in a fixed order by k_check_build
   }
@@ -1417,6 +1418,56 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// C = L L' for a dense column-major n x m matrix L (zero off the support of the observed pattern) by v_mfma_f64_16x16x4_f64,
+// one 16 x 16 tile of the lower triangle per wave and pass, operands straight from L2.  store(i, j, v) receives every entry of
+// the tile with i >= j inside the matrix (the caller mirrors).  Used where the output-stationary LDS formulation of k_global does
+// not fit (n > 144): there the per-entry walk over the CSR lists cost 4.8 ms per node at n = 200.
+// ---------------------------------------------------------------------------------------------------------
+template <class StoreF>
+__device__ __forceinline__ void mfma_LLt(const double* L, int n, int m, StoreF store) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int nt = (n + 15) >> 4, ntile = nt * (nt + 1) / 2;
+  const int m4 = m & ~3;
+  for (int tile = wv; tile < ntile; tile += nw) {
+    int ti = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int ia = (ti << 4) + li, jb = (tj << 4) + li;
+    const double ma = (ia < n) ? 1.0 : 0.0, mb = (jb < n) ? 1.0 : 0.0;
+    const double* La = L + ((ia < n) ? ia : n - 1);
+    const double* Lb = L + ((jb < n) ? jb : n - 1);
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    double aq[4], bq[4];
+    if (m4 >= 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { aq[u] = La[(size_t)(4 * u + lk) * n]; bq[u] = Lb[(size_t)(4 * u + lk) * n]; }
+    }
+    int k0 = 0;
+    for (; k0 + 16 <= m4; k0 += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double a = aq[u] * ma, bv = bq[u] * mb;
+        int kn = k0 + 16 + 4 * u + lk;
+        kn = (kn < m4) ? kn : kn - 16;              // re-reads a valid column at the end; the value is not used
+        aq[u] = La[(size_t)kn * n]; bq[u] = Lb[(size_t)kn * n];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+      }
+    }
+    for (; k0 < m; k0 += 4) {                       // remainder (< 16 columns), guarded
+      const int kk = k0 + lk;
+      const double a = (kk < m) ? La[(size_t)kk * n] * ma : 0.0, bv = (kk < m) ? Lb[(size_t)kk * n] * mb : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (ti << 4) + lk + 4 * r, j = (tj << 4) + li;
+      if (i < n && j < n && i >= j) store(i, j, acc[r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_small: the small cone  [S Vt; Vt' T] >= 0,  S = Q'(Y - D3)Q (r x r),  Vt - D3V (r x k),  T = I - D3T.
 //   mode SMALL_PROJ   : P3 = P_+(M3);  Q3 = P3 - M3 (>= 0: the multiplier direction);
 //                       dS = Q3_11, E3 = Q dS Q' (n x n), W3V = P3_12, W3T = P3_22, Q3V = Q3_12, Q3T = Q3_22
@@ -1700,15 +1751,12 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
       if (e < n * n) { const int i2 = e % n, i = e / n; tY[(size_t)i * n + i2] += 0.5 * g * accLL[kk]; }
     }
   } else {
-    for (int e = tid; e < n * n; e += T) {
-      const int i2 = e % n, i = e / n;            // consecutive threads -> consecutive i2: contiguous reads of Lambda[:, j]
-      double acc = 0.0;
-      for (int p = w.row_ptr[i]; p < w.row_ptr[i + 1]; ++p) {
-        const double* lj = lamD + (size_t)w.row_idx[p] * n;
-        acc += lj[i] * lj[i2];
-      }
-      tY[(size_t)i * n + i2] += 0.5 * g * acc;
-    }
+    // large orders: Lambda Lambda' as a dense MFMA product of the zero-padded copy (deterministic: one wave owns a tile)
+    mfma_LLt(lamD, n, m, [&](int i, int j, double v) {
+      const double t = 0.5 * g * v;
+      tY[(size_t)j * n + i] += t;
+      if (i != j) tY[(size_t)i * n + j] += t;
+    });
   }
   __syncthreads();
   for (int e = tid; e < n * n; e += T) tY[e] /= (rho * w.wY1[e]);
@@ -1884,13 +1932,22 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
   }
   __syncthreads();
   const double* al = w.alphaX + (size_t)b * w.nnz;
-  for (int j = 0; j < m; ++j) {
-    const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
-    for (int e = tid; e < c * c; e += T) {
-      int p = e % c, q = e / c;
-      M[(size_t)w.col_idx[off + q] * n + w.col_idx[off + p]] -= 0.5 * g * al[off + p] * al[off + q];
-    }
+  if (w.lamDX) {     // dense copy of the exact multipliers (k_colprox mode 1): one MFMA product instead of m scattered rank-one updates
+    mfma_LLt(w.lamDX + (size_t)b * m * n, n, m, [&](int i, int j, double v) {
+      const double t = 0.5 * g * v;
+      M[(size_t)j * n + i] -= t;
+      if (i != j) M[(size_t)i * n + j] -= t;
+    });
     __syncthreads();
+  } else {
+    for (int j = 0; j < m; ++j) {
+      const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
+      for (int e = tid; e < c * c; e += T) {
+        int p = e % c, q = e / c;
+        M[(size_t)w.col_idx[off + q] * n + w.col_idx[off + p]] -= 0.5 * g * al[off + p] * al[off + q];
+      }
+      __syncthreads();
+    }
   }
   double pen = 0.0;
   for (int j = 0; j < k; ++j) {
