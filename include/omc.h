@@ -213,7 +213,10 @@ int omc_comm_destroy(omc_instance* h);
 #define OMC_KERNEL_SMALL 5
 #define OMC_KERNEL_ACCEL 6
 #define OMC_KERNEL_CONESUB 7   /* k_cone_sub: the cone block by tracking the dominant 16-dimensional subspace */
-#define OMC_KERNEL_NCLASS 8
+#define OMC_KERNEL_CHECK_COL 8     /* certificate: exact f(Y) (one factorization per column, k_colprox mode 1) */
+#define OMC_KERNEL_CHECK_BUILD 9   /* certificate: Lagrangian matrix and constants (k_check_build) */
+#define OMC_KERNEL_HARVEST 10      /* finished slots: feasible U, separation eigenvector (OMC.jl:2466-2477), copy to the per-node outputs */
+#define OMC_KERNEL_NCLASS 11      /* OMC_KERNEL_CHECK = eigenvalues of the Lagrangian matrix + decisions */
 /* info[8]: solve seconds, total Jacobi sweeps of k_cone, rho, r_max, LDS flags (cone, global, small), R_max */
 int omc_last_solver_info(omc_instance* h, double* info);
 /* out[8] of the last omc_relax_solve: calls of k_cone_sub, its power steps, calls that fell back to the full eigendecomposition,

@@ -23,7 +23,7 @@ CUT_TYPES = {"linear": 0, "linear2": 1, "linear3": 2}
 DIR_CODES = {"left": 0, "middle": 1, "right": 2, "inner_left": 3, "inner_right": 4}
 BREAKPOINTS = {"smallest_1_eigvec": 1, "smallest_2_eigvec": 2}
 STATUS_NAMES = {0: "OPTIMAL", 1: "SLOW_PROGRESS", 2: "TIME_LIMIT", 3: "INFEASIBLE"}
-KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small", "accel", "cone_sub"]
+KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small", "accel", "cone_sub", "check_col", "check_build", "harvest"]
 
 
 def default_params(**kw) -> RelaxParams:

@@ -70,7 +70,7 @@ struct omc_instance {
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
   DevBuf bobjcol, baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
-  DevBuf bslotlist, bgap, bvotes, blamDX;
+  DevBuf bslotlist, bgap, bvotes, blamDX, bXsC, bsubSC, bsubIC;
   DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow, bXs, bsubS, bsubI;
   long long sub_tot[8] = {0};
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
@@ -201,7 +201,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
-                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes, &h->blamDX,
+                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes, &h->blamDX, &h->bXsC, &h->bsubSC, &h->bsubIC,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
@@ -453,6 +453,13 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.sub_adapt = getenv("OMC_SUB_ADAPT") ? atof(getenv("OMC_SUB_ADAPT")) : 1e-3;
     w.sub_debug = getenv("OMC_SUB_DEBUG") ? atoi(getenv("OMC_SUB_DEBUG")) : 0;
     w.sub_enable = 0;     // decided below, once the cone kernel variant is known
+    ENS(h->bXsC, sB * w.np16 * 16 * 8); ENS(h->bsubSC, sB * 18 * 8); ENS(h->bsubIC, sB * 3 * sizeof(int));
+    HIPCHK(hipMemsetAsync(h->bXsC.p, 0, sB * w.np16 * 16 * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->bsubSC.p, 0, sB * 18 * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->bsubIC.p, 0, sB * 3 * sizeof(int), h->stream));
+    w.XsC = h->bXsC.as<double>(); w.sub_thetaC = h->bsubSC.as<double>(); w.trMc = h->bsubSC.as<double>() + sB * 16; w.lb_est = h->bsubSC.as<double>() + sB * 17;
+    w.sub_onC = h->bsubIC.as<int>(); w.confirm = h->bsubIC.as<int>() + sB; w.sep_done = nullptr;
+    w.cert_enable = 0;
   }
   if (!getenv("OMC_COLD_CHECK")) {   // warm-started eigenvalues for the certificate matrix
     ENS(h->bMbufC, sB * w.np16 * w.np16 * 8); ENS(h->bVrowC, sB * w.np16 * w.np16 * 8); ENS(h->bchkS, sB * 8); ENS(h->bchkI, sB * sizeof(int));
@@ -579,6 +586,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       h->ws_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;   // WS_JROWS
       // subspace tracking needs the warm-started kernel as its seed / fall-back and at least 3 x 16 rows
       w.sub_enable = (h->ws_lpp && n >= 48 && omc_cone_sub_lds(w.np16) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE")) ? 1 : 0;
+      w.cert_enable = (w.sub_enable && w.MbufC && getenv("OMC_CERT_SUB")) ? 1 : 0;
+      w.sep_done = (w.sub_enable && !getenv("OMC_NO_SEP_SUB")) ? h->bsubIC.as<int>() + 2 * sB : nullptr;   // opt-in: measured no gain (the eigenvalues are not what the check spends its time on) and fewer rigorous samples of the bound
     }
     h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8 + (size_t)h->nnz * 4 + 16;   // n*m >= n*n: the region also stages Lambda
     h->glob_use_lds = h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS;   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
@@ -714,13 +723,22 @@ int omc_relax_solve(omc_instance* h) {
     wait_main = true;
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     timed_out = el > P.time_limit;
-    TIMED(OMC_KERNEL_CHECK, nactive, {
+    TIMED(OMC_KERNEL_CHECK_COL, nactive, {
       omc_launch_check_zero(&w, s);
       omc_launch_colprox(&w, 1, s);
-      omc_launch_check_build(&w, s);
-      if (h->ws_lpp && w.MbufC) { OmcWS wc = w; wc.ws_mode = 1; omc_launch_cone_ws(&wc, h->ws_lpp, h->ws_use_lds, h->ws_lds, s); }
-      else omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
-      omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, s);      // per-slot iteration cap is applied on the device
+    });
+    TIMED(OMC_KERNEL_CHECK_BUILD, nactive, omc_launch_check_build(&w, s));
+    TIMED(OMC_KERNEL_CHECK, nactive, {
+      if (w.cert_enable) {        // estimate by the tracked block, decisions, rigorous evaluation of the slots that are about to finish
+        omc_launch_cert_sub(&w, s);
+        omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, 0, s);
+        OmcWS wc = w; wc.ws_mode = 1; omc_launch_cone_ws(&wc, h->ws_lpp, h->ws_use_lds, h->ws_lds, s);
+        omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, 1, s);
+      } else {
+        if (h->ws_lpp && w.MbufC) { OmcWS wc = w; wc.ws_mode = 1; omc_launch_cone_ws(&wc, h->ws_lpp, h->ws_use_lds, h->ws_lds, s); }
+        else omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
+        omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, 2, s);      // per-slot iteration cap is applied on the device
+      }
       if (w.bump_max > 0) omc_launch_rho_rescale(&w, s);
       if (w.accel) omc_launch_aa(&w, s);      // after the certificate (computed on an image of the map), skips finished slots
     });
@@ -754,8 +772,9 @@ int omc_relax_solve(omc_instance* h) {
     for (int b = 0; b < S; ++b) if (node_of[b] >= 0 && done[b]) { fin[b] = 1; ++nfin; }
     if (nfin) {
       int rc = push_flags(init, fin); if (rc) return rc;
-      TIMED(OMC_KERNEL_CHECK, nfin, {
+      TIMED(OMC_KERNEL_HARVEST, nfin, {
         omc_launch_small(&w, SMALL_RECOVER, h->small_use_lds, h->small_lds, s);   // a U with U U' <= Y and the same Q'U
+        if (w.sep_done) omc_launch_sep_sub(&w, s);                                // separation vector from the tracked block where there is one
         omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, s);           // separation vector (OMC.jl:2466-2477)
         omc_launch_harvest(&w, s);
       });

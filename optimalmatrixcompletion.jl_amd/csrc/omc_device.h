@@ -80,6 +80,9 @@ struct OmcWS {
   double* trM;            // B: trace of Mbuf (with fro2 it bounds the untracked part of the spectrum)
   int *sub_wait, *sub_nfail; // B: iterations left before the subspace is tried again after a failure ; failures so far (back-off)
   int *sub_on, *cone_done;   // B: slot follows the subspace ; this iteration's W1 has been written by k_cone_sub
+  // certificate estimator (k_cone_sub<1>): block of the most negative eigenvectors of Mchk, its Ritz values (of -Mchk), trace of MbufC
+  int* sep_done;          // B: the separation vector of this harvested slot came from the tracked block (k_cone_sub<2>); NULL = feature off
+  int cert_enable; double *XsC, *sub_thetaC, *trMc, *lb_est; int *sub_onC, *confirm;
   int* sub_stat;          // B * 8: calls, power steps, failures (fall back to the full decomposition), seeds, failures by cause (too many positive Ritz values, step cap, Cholesky), Rayleigh-Ritz passes
   // rows
   int* R;                 // B
@@ -125,7 +128,9 @@ void omc_launch_cone_sub(const OmcWS* w, hipStream_t s);
 size_t omc_cone_sub_lds(int np16);
 void omc_launch_check_zero(const OmcWS* w, hipStream_t s);
 void omc_launch_check_build(const OmcWS* w, hipStream_t s);
-void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s);
+void omc_launch_check_final(const OmcWS* w, int last, int phase, hipStream_t s);
+void omc_launch_cert_sub(const OmcWS* w, hipStream_t s);
+void omc_launch_sep_sub(const OmcWS* w, hipStream_t s);
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s);
 void omc_launch_harvest(const OmcWS* w, hipStream_t s);
 void omc_launch_aa(const OmcWS* w, hipStream_t s);

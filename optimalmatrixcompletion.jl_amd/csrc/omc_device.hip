@@ -83,7 +83,7 @@ __global__ void k_setup(OmcWS w) {
       w.Vrow[(size_t)b * NP * NP + e] = 0.0;
     }
     if (tid == 0) {
-      w.fro2[b] = d0 * d0 * n; w.trM[b] = d0 * n; w.sub_on[b] = 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
+      w.fro2[b] = d0 * d0 * n; w.trM[b] = d0 * n; w.sub_on[b] = 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
     }
   }
   for (int e = tid; e < n * k; e += T) w.U[(size_t)b * n * k + e] = 0.0;
@@ -752,6 +752,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
   const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b] && mode != CONE_SEP && mode != CONE_TOPK) return;
   if ((mode == CONE_SEP || mode == CONE_TOPK) && !w.fin[b]) return;
+  if (mode == CONE_SEP && w.sep_done && w.sep_done[b]) return;      // k_cone_sub<2> has delivered the separation vector
   const int n = w.n, k = w.k;
   const int N = n;
   const int Np = (N + 1) & ~1, ld = Np | 1;
@@ -884,6 +885,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
   if (!w.ws_mode && w.sub_enable && w.cone_done[b]) return;      // k_cone_sub has already written W1 for this iteration
+  if (w.ws_mode && w.cert_enable && !w.confirm[b]) return;       // the estimate of k_cone_sub<1> is enough for this check
   const int n = w.n, N = n, NP = w.np16;
   const int Np = (N + 1) & ~1;
   // lane lg of a pair group owns the CONTIGUOUS rows [lg*rpl, (lg+1)*rpl): 16-byte LDS reads, rpl even, ld even
@@ -1038,6 +1040,30 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   if (tid == 0) vvalid[b] = 1;
   STAMP(2);
   if (evals_only) {
+    if (w.cert_enable && N >= 3 * SUBP) {     // seed the certificate block with the SUBP most negative eigenpairs (largest of -Mchk)
+      double* lam_s = (double*)(sel + Np + (Np & 1));
+      for (int t = tid; t < N; t += T) lam_s[t] = sqrt(ev[t]) - sigma;
+      __syncthreads();
+      if (tid == 0) {
+        for (int j = 0; j < SUBP; ++j) {
+          int bi = -1; double bl = 1e300;
+          for (int t = 0; t < N; ++t) {
+            bool used = false;
+            for (int q = 0; q < j; ++q) if (s_top[q] == t) used = true;
+            if (!used && lam_s[t] < bl) { bl = lam_s[t]; bi = t; }
+          }
+          s_top[j] = bi;
+          w.sub_thetaC[(size_t)b * SUBP + j] = -bl;
+        }
+        w.sub_onC[b] = 1;
+      }
+      __syncthreads();
+      double* Xg = w.XsC + (size_t)b * NP * SUBP;
+      for (int e = tid; e < SUBP * NP; e += T) {
+        const int j = e / NP, r = e - j * NP;
+        Xg[e] = (r < N) ? Gm[(size_t)s_top[j] * ld + r] * rsqrt(ev[s_top[j]]) : 0.0;
+      }
+    }
     if (tid == 0) {
       const int k = w.k;
       double best[8]; const int kk2 = (k < 8) ? k : 8;
@@ -1135,13 +1161,27 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
 // eigenvectors whenever it finds at most SUBP - SUBG positive eigenvalues.
 // ---------------------------------------------------------------------------------------------------------
 
+// MODE 0: the cone block (above).  MODE 1: the certificate -- the k most negative eigenvalues of the Lagrangian matrix Mchk (k_check_build)
+// are the k largest of -Mchk, followed by the same machinery on its own block XsC.  Ritz values are lower bounds of those, so the
+// result is an ESTIMATE of the dual bound (optimistic by the square of the residual): k_check_final uses it for its decisions and every
+// node that is about to finish gets the rigorous eigendecomposition (k_cone_ws, ws_mode = 1) before anything is reported (w.confirm).
+template <int MODE>
 __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   extern __shared__ double smem[];
   __shared__ int s_flag, s_nsel;
   __shared__ double s_shift;
-  const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
-  if (w.done[b] || !w.sub_on[b]) return;
-  if (w.sub_wait[b] > 0) { if (threadIdx.x == 0) w.sub_wait[b] -= 1; return; }     // backing off after a failed call
+  const int b = (MODE == 0) ? slot_of(w, blockIdx.x) : (int)blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (MODE == 2) {
+    if (!w.fin[b] || !w.sub_on[b]) return;      // separation of a harvested slot, seeded by the block that followed Y - D1
+  } else {
+    if (w.done[b]) return;
+    if (MODE == 0) {
+      if (!w.sub_on[b]) return;
+      if (w.sub_wait[b] > 0) { if (threadIdx.x == 0) w.sub_wait[b] -= 1; return; }     // backing off after a failed call
+    } else {
+      if (!w.sub_onC[b]) { if (threadIdx.x == 0) w.confirm[b] = 1; return; }           // no block yet: the full kernel evaluates (and seeds)
+    }
+  }
   const int n = w.n, NP = w.np16, nt = NP >> 4, LD = NP + 2;
   const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   double* Xa = smem;                     // SUBP x LD   X (column j at Xa + j*LD)
@@ -1154,14 +1194,16 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   double* red = evj + 16;                // 32
   double* wgt = red + 32;                // 16
   int* sel = (int*)(wgt + 16);           // 16
-  const double* Mb = w.Mbuf + (size_t)b * NP * NP;
-  double* Xg = w.Xs + (size_t)b * NP * SUBP;
-  const double fro2 = w.fro2[b], nF = sqrt(fro2), trM = w.trM[b];
+  const double* Mb = ((MODE == 1) ? w.MbufC : w.Mbuf) + (size_t)b * NP * NP;      // MODE 2: k_sep_prepare has put Y - U U' there
+  double* Xg = ((MODE == 1) ? w.XsC : w.Xs) + (size_t)b * NP * SUBP;
+  double* thg = ((MODE == 1) ? w.sub_thetaC : w.sub_theta) + (size_t)b * SUBP;
+  constexpr double sgn = (MODE == 1) ? -1.0 : 1.0;          // MODE 1 works on -Mchk
+  const double fro2 = (MODE == 1) ? w.fro2c[b] : w.fro2[b], nF = sqrt(fro2), trM = (MODE == 1) ? -w.trMc[b] : w.trM[b];
   // inexact projections are harmless while the ADMM iterate itself still moves (errors proportional to the step are summable):
   // the residual target follows the last dual residual ||Y_new - Y_old|| down to sub_tol
-  const double tol_eff = (w.sub_adapt > 0.0) ? fmin(1e-6, fmax(w.sub_tol, w.sub_adapt * w.rd[b] / fmax(nF, 1e-300))) : w.sub_tol;
+  const double tol_eff = (MODE == 2) ? 1e-11 : (MODE == 1) ? 1e-9 : ((w.sub_adapt > 0.0) ? fmin(1e-6, fmax(w.sub_tol, w.sub_adapt * w.rd[b] / fmax(nF, 1e-300))) : w.sub_tol);
   for (int e = tid; e < SUBP * NP; e += T) { const int j = e / NP, r = e - j * NP; Xa[(size_t)j * LD + r] = Xg[e]; }
-  if (tid < SUBP) th[tid] = w.sub_theta[(size_t)b * SUBP + tid];
+  if (tid < SUBP) th[tid] = thg[tid];
   __syncthreads();
 
   // Z (+ s X) = M X for the row tiles of this wave (up to three, computed together: independent accumulators and twelve loads in
@@ -1183,7 +1225,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       for (int k0 = 0; k0 < NP; k0 += 16) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const double x0 = a0[u], x1 = a1[u], x2 = a2[u], bv = Xb[k0 + 4 * u + lk];
+          const double x0 = sgn * a0[u], x1 = sgn * a1[u], x2 = sgn * a2[u], bv = Xb[k0 + 4 * u + lk];
           int kn = k0 + 16 + 4 * u + lk;
           kn = (kn < NP) ? kn : kn - NP;               // wrapped prefetch of the last chunk is never used
           const size_t o = (size_t)kn * NP;
@@ -1224,9 +1266,10 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0;
 #define SUBSTAMP(slot) do { if (prof) { __syncthreads(); if (tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); w.stamps[slot] += (double)(t_ - tprev); tprev = t_; } } } while (0)
   SUBSTAMP(0);
+  bool skip_steps = (MODE == 2);      // MODE 2: the block belongs to another matrix -- Rayleigh-Ritz first, its Ritz values then set the shift
   while (true) {
     // ---- `chunk` power steps with the shift that centres the untracked part of the spectrum --------------------------------
-    if (wv == 0) {
+    if (wv == 0 && !skip_steps) {
       const double tj = (lane < SUBP) ? th[lane] : 0.0;
       const double st = wave_sum(tj), st2 = wave_sum(tj * tj);
       const double nr = (double)(n - SUBP);
@@ -1247,7 +1290,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
     __syncthreads();
     const double shift = s_shift;
     SUBSTAMP(1);
-    for (int c = 0; c < chunk && !fail; ++c) {
+    for (int c = 0; c < chunk && !fail && !skip_steps; ++c) {
       mul_MX(shift);
       __syncthreads();
       SUBSTAMP(2);
@@ -1311,6 +1354,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       ++steps;
     }
     if (fail) break;
+    skip_steps = false;
     // ---- Rayleigh-Ritz ------------------------------------------------------------------------------------------------------
     mul_MX(0.0);
     __syncthreads();
@@ -1366,7 +1410,26 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       if (lane == 0) evj[t] = sqrt(a);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (MODE >= 1) {
+      if (tid == 0) {      // only the largest Ritz values have to be accurate: MODE 1 the k most negative eigenvalues of Mchk, MODE 2 two
+        int bad = 0; double used[8]; const int kk = (MODE == 2) ? 2 : ((w.k < 8) ? w.k : 8);
+        double ssum = 0.0;
+        for (int q = 0; q < kk; ++q) {
+          int bi = -1; double bl = -1e300;
+          for (int t = 0; t < SUBP; ++t) {
+            bool u_ = false;
+            for (int q2 = 0; q2 < q; ++q2) if (used[q2] == (double)t) u_ = true;
+            if (!u_ && th[t] > bl) { bl = th[t]; bi = t; }
+          }
+          used[q] = (double)bi;
+          if (!(evj[bi] <= tol_eff * fmax(nF, 1e-300))) bad = 1;
+          ssum += fmax(bl, 0.0);
+          if (MODE == 2) sel[q] = bi;
+        }
+        s_flag = bad ? 0 : 1;
+        s_shift = -ssum;         // estimate of sum_{i <= k} min(eig_i(Mchk), 0)
+      }
+    } else if (tid == 0) {
       // a Ritz pair (theta, x) contaminated by an untracked eigenvector (eigenvalue <= gneg < 0) by an angle phi has residual
       // ~ (theta - gneg) phi and perturbs W1 by ~ theta phi: pairs with a small theta may carry a proportionally larger residual
       int nk = 0, bad = 0; double gneg = -1e300;
@@ -1390,6 +1453,36 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       fail = 2; break;
     }
   }
+  if (MODE == 2) {
+    if (!ok) return;                      // sep_done stays 0: the cold kernel computes the separation vector
+    // lambda_min(U U' - Y) = -theta_1; canonical sign (largest-magnitude entry positive) and the smallest_2 mix of OMC.jl:2471-2476
+    const int i1 = sel[0], i2 = sel[1];
+    __shared__ double s_sg[2], s_wt[2];
+    if (tid == 0) {
+      const double l1 = -th[i1], l2 = -th[i2];
+      w.lmin[2 * b] = l1; w.lmin[2 * b + 1] = l2;
+      for (int q = 0; q < 2; ++q) {
+        const double* g = Xa + (size_t)sel[q] * LD;
+        int a1 = 0;
+        for (int r = 1; r < n; ++r) if (fabs(g[r]) > fabs(g[a1])) a1 = r;
+        s_sg[q] = (g[a1] >= 0.0) ? 1.0 : -1.0;
+      }
+      if (w.breakpoints == 2 && l2 < -1e-10) { const double nn = sqrt(l1 * l1 + l2 * l2); s_wt[0] = fabs(l1) / nn; s_wt[1] = fabs(l2) / nn; }
+      else { s_wt[0] = 1.0; s_wt[1] = 0.0; }
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += T) w.bx[(size_t)b * n + r] = s_wt[0] * s_sg[0] * Xa[(size_t)i1 * LD + r] + s_wt[1] * s_sg[1] * Xa[(size_t)i2 * LD + r];
+    if (tid == 0) w.sep_done[b] = 1;
+    return;
+  }
+  if (MODE == 1) {
+    if (!ok) { if (tid == 0) { w.confirm[b] = 1; w.sub_onC[b] = 0; } return; }      // the full kernel evaluates this slot and seeds a new block
+    const double est = s_shift;
+    for (int e = tid; e < SUBP * NP; e += T) { const int j = e / NP, r = e - j * NP; Xg[e] = Xa[(size_t)j * LD + r]; }
+    if (tid < SUBP) thg[tid] = th[tid];
+    if (tid == 0) { w.evsum[b] = est; w.confirm[b] = 0; }
+    return;
+  }
   if (tid == 0) {
     atomicAdd(&w.sub_stat[8 * b + 0], 1); atomicAdd(&w.sub_stat[8 * b + 1], steps); atomicAdd(&w.sub_stat[8 * b + 7], nrr);
     if (!ok) {
@@ -1400,7 +1493,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   }
   if (!ok) return;                       // cone_done stays 0: the full kernel projects this slot (and re-seeds X)
   for (int e = tid; e < SUBP * NP; e += T) { const int j = e / NP, r = e - j * NP; Xg[e] = Xa[(size_t)j * LD + r]; }
-  if (tid < SUBP) w.sub_theta[(size_t)b * SUBP + tid] = th[tid];
+  if (tid < SUBP) thg[tid] = th[tid];
   if (tid == 0) {
     int c = 0;
     for (int t = 0; t < SUBP; ++t) if (th[t] > 0.0) { sel[c] = t; wgt[c] = fmin(th[t], 1.0); ++c; }
@@ -1415,6 +1508,28 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   SUBSTAMP(11);
   if (prof && tid == 0) { w.stamps[12] += 1.0; w.stamps[13] += steps; w.stamps[14] += nrr; }
   if (tid == 0) w.cone_done[b] = 1;
+}
+
+// Mbuf <- Y - U U' (zero padded), fro2, trace for the harvested slots whose separation vector k_cone_sub<2> will compute
+__global__ void __launch_bounds__(256) k_sep_prepare(OmcWS w) {
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (tid == 0 && w.fin[b]) w.sep_done[b] = 0;
+  if (!w.fin[b] || !w.sub_on[b]) return;
+  const int n = w.n, k = w.k, NP = w.np16;
+  const double* Y = w.Y + (size_t)b * n * n;
+  const double* U = w.U + (size_t)b * n * k;
+  double* Mb = w.Mbuf + (size_t)b * NP * NP;
+  double fr2 = 0.0, tr1 = 0.0;
+  for (int e = tid; e < n * n; e += T) {
+    const int i = e % n, j = e / n;
+    double s2 = 0.0;
+    for (int t = 0; t < k; ++t) s2 += U[(size_t)t * n + i] * U[(size_t)t * n + j];
+    const double mv = 0.5 * (Y[e] + Y[(size_t)i * n + j]) - s2;
+    Mb[(size_t)j * NP + i] = mv; fr2 += mv * mv; if (i == j) tr1 += mv;
+  }
+  fr2 = block_sum(fr2, red); tr1 = block_sum(tr1, red);
+  if (tid == 0) { w.fro2[b] = fr2; w.trM[b] = tr1; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1968,57 +2083,76 @@ __global__ void __launch_bounds__(512) k_check_build(OmcWS w) {
   }
   if (w.MbufC) {   // zero-padded copy + Frobenius norm for the warm-started eigenvalue kernel
     const int NP = w.np16;
-    double fr2 = 0.0;
+    double fr2 = 0.0, tr1 = 0.0;
     for (int e = tid; e < n * n; e += T) {
       const int i = e % n, j = e / n;
       const double mv = 0.5 * (M[e] + M[(size_t)i * n + j]);
-      w.MbufC[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv;
+      w.MbufC[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv; if (i == j) tr1 += mv;
     }
     fr2 = block_sum(fr2, red);
-    if (tid == 0) w.fro2c[b] = fr2;
+    tr1 = block_sum(tr1, red);
+    if (tid == 0) { w.fro2c[b] = fr2; w.trMc[b] = tr1; }
   }
 }
 
-__global__ void k_check_final(OmcWS w, int last) {
+// phase 2: the bound of this check is rigorous for every slot (no certificate estimator).  With the estimator (k_cone_sub<1>):
+// phase 0 decides on the ESTIMATED bound for the slots that have one; a slot that would finish (or that has no estimate) is only
+// flagged (w.confirm) and nothing is committed for it; k_cone_ws then evaluates the flagged slots rigorously and phase 1 repeats the
+// logic for them with that bound.  w.lb (the bound that is reported) only ever receives rigorous values.
+__global__ void k_check_final(OmcWS w, int last, int phase) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= w.B || w.done[b]) return;
-  double lbv = w.c0[b] + w.evsum[b] - w.cpen[b] + w.cst[b];
-  if (lbv > w.lb[b]) w.lb[b] = lbv;
+  if (phase == 0 && w.confirm[b]) return;
+  if (phase == 1 && !w.confirm[b]) return;
+  const bool est = (phase == 0);
+  const double lbv = w.c0[b] + w.evsum[b] - w.cpen[b] + w.cst[b];
+  const double lb_rig = w.lb[b];
+  const double lb_dec = fmax(est ? fmax(lb_rig, w.lb_est[b]) : lb_rig, lbv);      // the bound the decisions of this check use
   const double obj = w.obj[b];
-  w.objout[b] = obj;
   const double Nk = (double)(w.n + w.k);
   const bool feas = w.rp[b] <= w.eps_feas * sqrt(Nk) && !w.rowov[b];   // rows deferred by the NNQP cap: not a feasible point
+  int term = -1;
+  int stall_new = w.stall[b], votes_new = w.slow_votes[b];
+  double gnow = 0.0, q = 1.0;
   // two-sided: the primal value of an eps-feasible iterate can sit BELOW the certified bound (by ~ residual x ||multipliers||); such a
   // point is not within eps_gap of the optimum value, so the node keeps iterating until feasibility has pulled the value up
-  if (fabs(obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && feas) { w.done[b] = 1; w.status[b] = OMC_ST_OPTIMAL; return; }
+  if (fabs(obj - lb_dec) <= w.eps_gap * fmax(1.0, fabs(obj)) && feas) term = OMC_ST_OPTIMAL;
   // f(Y) <= f(0) = 1/2 ||A_Omega||^2 on the feasible set: a larger certified bound proves infeasibility
-  if (w.lb[b] > 0.5 * w.sumA2 * (1.0 + 1e-9) + 1e-9) { w.done[b] = 1; w.status[b] = OMC_ST_INFEASIBLE; return; }
-  // stationary primal value and no progress of the bound: give up with values (MOI.SLOW_PROGRESS)
-  if (fabs(obj - w.objprev[b]) <= 1e-7 * fmax(1.0, fabs(obj)) && lbv <= w.lbprev[b] + 1e-7 * fmax(1.0, fabs(obj))) w.stall[b] += 1;
-  else w.stall[b] = 0;
-  w.objprev[b] = obj; w.lbprev[b] = w.lb[b];
-  if (w.stall[b] >= w.stall_checks) {
-    const bool okgap = fabs(obj - w.lb[b]) <= w.eps_gap * fmax(1.0, fabs(obj)) && w.rp[b] <= 10.0 * w.eps_feas * sqrt(Nk) && !w.rowov[b];
-    w.done[b] = 1; w.status[b] = okgap ? OMC_ST_OPTIMAL : OMC_ST_SLOW; return;
+  else if (lb_dec > 0.5 * w.sumA2 * (1.0 + 1e-9) + 1e-9) term = OMC_ST_INFEASIBLE;
+  else {
+    // stationary primal value and no progress of the bound: give up with values (MOI.SLOW_PROGRESS)
+    if (fabs(obj - w.objprev[b]) <= 1e-7 * fmax(1.0, fabs(obj)) && lbv <= w.lbprev[b] + 1e-7 * fmax(1.0, fabs(obj))) stall_new += 1;
+    else stall_new = 0;
+    if (stall_new >= w.stall_checks) {
+      const bool okgap = fabs(obj - lb_dec) <= w.eps_gap * fmax(1.0, fabs(obj)) && w.rp[b] <= 10.0 * w.eps_feas * sqrt(Nk) && !w.rowov[b];
+      term = okgap ? OMC_ST_OPTIMAL : OMC_ST_SLOW;
+    } else if (last) term = last;
+    else if (w.iters[b] >= w.max_iters) term = OMC_ST_SLOW;
+    else if (w.early_stop_factor > 0.0) {
+      // early SLOW_PROGRESS: the gap of a crawling node decays geometrically (measured: a constant factor per check).  With q the
+      // exponential average of gap_now / gap_previous, closing the rest takes log(gap / target) / log(1 / q) checks; when that exceeds
+      // early_stop_factor x the checks left before max_iters the node cannot be certified any more -- its values and its (valid) bound
+      // are returned now instead of after the iteration cap.  Eight consecutive such predictions are required.
+      const double target = w.eps_gap * fmax(1.0, fabs(obj));
+      gnow = obj - lb_dec;
+      const double gp = w.gap_prev[b];
+      q = (gp < 1e299 && gp > 0.0 && gnow > 0.0) ? 0.5 * w.gap_rate[b] + 0.5 * fmin(gnow / gp, 2.0) : 1.0;
+      const double left = (double)(w.max_iters - w.iters[b]) / (double)w.check_every;
+      const double need = (q < 1.0) ? log(fmax(gnow, target) / target) / -log(q) : 1e300;
+      const bool hopeless = w.iters[b] >= w.early_stop_after && gnow > target && need > w.early_stop_factor * left;   // an infeasible iterate understates the gap: no feasibility condition
+      votes_new = hopeless ? votes_new + 1 : 0;
+      if (votes_new >= 8) term = OMC_ST_SLOW;
+    }
   }
-  if (last) { w.done[b] = 1; w.status[b] = last; return; }
-  if (w.iters[b] >= w.max_iters) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }
-  // early SLOW_PROGRESS: the gap of a crawling node decays geometrically (measured: a constant factor per check).  With q the
-  // exponential average of gap_now / gap_previous, closing the rest takes log(gap / target) / log(1 / q) checks; when that exceeds
-  // early_stop_factor x the checks left before max_iters the node cannot be certified any more -- its values and its (valid) bound
-  // are returned now instead of after the iteration cap.  Eight consecutive such predictions are required.
-  if (w.early_stop_factor > 0.0) {
-    const double target = w.eps_gap * fmax(1.0, fabs(obj));
-    const double gnow = obj - w.lb[b];
-    const double gp = w.gap_prev[b];
-    const double q = (gp < 1e299 && gp > 0.0 && gnow > 0.0) ? 0.5 * w.gap_rate[b] + 0.5 * fmin(gnow / gp, 2.0) : 1.0;
-    w.gap_prev[b] = gnow; w.gap_rate[b] = q;
-    const double left = (double)(w.max_iters - w.iters[b]) / (double)w.check_every;
-    const double need = (q < 1.0) ? log(fmax(gnow, target) / target) / -log(q) : 1e300;
-    const bool hopeless = w.iters[b] >= w.early_stop_after && gnow > target && need > w.early_stop_factor * left;   // an infeasible iterate understates the gap: no feasibility condition
-    w.slow_votes[b] = hopeless ? w.slow_votes[b] + 1 : 0;
-    if (w.slow_votes[b] >= 8) { w.done[b] = 1; w.status[b] = OMC_ST_SLOW; return; }
-  }
+  if (est && term >= 0) { w.confirm[b] = 1; return; }      // nothing committed: phase 1 decides on the rigorous bound
+  // ---- commit ----------------------------------------------------------------------------------------------------------------
+  if (!est) w.lb[b] = fmax(lb_rig, lbv);
+  w.lb_est[b] = fmax(w.lb_est[b], lbv);
+  w.objout[b] = obj;
+  w.stall[b] = stall_new; w.objprev[b] = obj; w.lbprev[b] = lb_dec;
+  if (w.early_stop_factor > 0.0 && term < 0) { w.gap_prev[b] = gnow; w.gap_rate[b] = q; w.slow_votes[b] = votes_new; }
+  if (phase == 1) w.confirm[b] = 0;
+  if (term >= 0) { w.done[b] = 1; w.status[b] = term; return; }
   // penalty bump: crawling nodes with active cuts show rp >> rd
   w.bfac[b] = 1.0;
   if (w.bump_max > 0 && w.iters[b] >= w.bump_after && w.nbump[b] < w.bump_max && w.iters[b] - w.lastbump[b] >= w.bump_gap &&
@@ -2341,7 +2475,14 @@ void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, 
 }
 size_t omc_cone_sub_lds(int np16) { return ((size_t)2 * SUBP * (np16 + 2) + 4 * 256 + 2 * 16 * 17 + 16 + 16 + 32 + 16 + 8) * sizeof(double); }
 void omc_launch_cone_sub(const OmcWS* w, hipStream_t s) {
-  hipLaunchKernelGGL(k_cone_sub, dim3(w->nB), dim3(256), omc_cone_sub_lds(w->np16), s, *w);
+  hipLaunchKernelGGL(k_cone_sub<0>, dim3(w->nB), dim3(256), omc_cone_sub_lds(w->np16), s, *w);
+}
+void omc_launch_sep_sub(const OmcWS* w, hipStream_t s) {
+  hipLaunchKernelGGL(k_sep_prepare, dim3(w->B), dim3(256), 0, s, *w);
+  hipLaunchKernelGGL(k_cone_sub<2>, dim3(w->B), dim3(256), omc_cone_sub_lds(w->np16), s, *w);
+}
+void omc_launch_cert_sub(const OmcWS* w, hipStream_t s) {
+  hipLaunchKernelGGL(k_cone_sub<1>, dim3(w->B), dim3(256), omc_cone_sub_lds(w->np16), s, *w);
 }
 void omc_launch_small(const OmcWS* w, int mode, int use_lds, size_t lds_bytes, hipStream_t s) {
   if (use_lds) hipLaunchKernelGGL(k_small<true>, dim3(w->nB), dim3(256), lds_bytes, s, *w, mode);
@@ -2353,8 +2494,8 @@ void omc_launch_global(const OmcWS* w, int use_lds, size_t lds_bytes, hipStream_
 }
 void omc_launch_check_zero(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_zero_check, dim3((w->B + 63) / 64), dim3(64), 0, s, *w); }
 void omc_launch_check_build(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_check_build, dim3(w->B), dim3(512), 0, s, *w); }
-void omc_launch_check_final(const OmcWS* w, int last, hipStream_t s) {
-  hipLaunchKernelGGL(k_check_final, dim3((w->B + 63) / 64), dim3(64), 0, s, *w, last);
+void omc_launch_check_final(const OmcWS* w, int last, int phase, hipStream_t s) {
+  hipLaunchKernelGGL(k_check_final, dim3((w->B + 63) / 64), dim3(64), 0, s, *w, last, phase);
 }
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_rho_rescale, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_harvest(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_harvest, dim3(w->B), dim3(256), 0, s, *w); }
@@ -2372,7 +2513,9 @@ int omc_set_max_lds(void) {
   hipError_t e2 = hipFuncSetAttribute((const void*)k_global<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS - 8 * 1024);   // ~19 KB of static LDS (NNQP scratch)
   hipError_t e3 = hipFuncSetAttribute((const void*)k_colprox, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
   hipError_t e4 = hipFuncSetAttribute((const void*)k_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
-  (void)hipFuncSetAttribute((const void*)k_cone_sub, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_sub<0>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_sub<1>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
+  (void)hipFuncSetAttribute((const void*)k_cone_sub<2>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS);
 #define WS_ATTR(L, R) (void)hipFuncSetAttribute((const void*)k_cone_ws<L, true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, OMC_MAX_DYN_LDS)
 #define WS_ATTR_ALL(L) WS_ATTR(L, 0); WS_ATTR(L, 4); WS_ATTR(L, 5); WS_ATTR(L, 6); WS_ATTR(L, 7); WS_ATTR(L, 8)
   WS_ATTR_ALL(4); WS_ATTR_ALL(8); WS_ATTR_ALL(16);
