@@ -69,7 +69,7 @@ def cpu_baseline_legs(A, mask, gamma, k, cut_type, rho_scale, nodes, depth):
     t1 = time.perf_counter()
     one = _cpu_worker((A, mask, gamma, k, cut_type, rho_scale, nodes))
     t_one = time.perf_counter() - t1
-    workers = min(nproc, 32)
+    workers = min(nproc, 16)        # the CPU share of a one-GPU box
     sample = [nodes[i % len(nodes)] for i in range(workers)]
     ctx = mp.get_context("spawn")
     t1 = time.perf_counter()

@@ -691,31 +691,70 @@ int omc_relax_solve(omc_instance* h) {
   bool timed_out = false;
   h->total_sweeps = 0;
   bool wait_main = true;     // group streams must wait for the work queued on the main stream (setup, checks, refills)
+  // Small batches are launch-bound (batch 1: ~190 us of launches, event records and waits around ~115 us of kernels per iteration):
+  // the body of an iteration (fork, three concurrent blocks, join, global step) is captured once into a hipGraph and replayed; it is
+  // captured again only when the number of live slots changes.  Per-kernel HIP-event timing is not available inside a graph, so the
+  // large batches that the bench times keep the eager path.
+  const int graph_max = getenv("OMC_GRAPH_MAX") ? atoi(getenv("OMC_GRAPH_MAX")) : 128;
+  hipGraphExec_t gexec[2] = {nullptr, nullptr}; int gexec_n = -1;
+  struct GraphGuard { hipGraphExec_t* e; ~GraphGuard() { for (int q = 0; q < 2; ++q) if (e[q]) (void)hipGraphExecDestroy(e[q]); } } gguard{gexec};
+  auto body = [&](int g, const OmcWS& wg, bool timed, bool with_aa) -> int {
+    hipStream_t sm = multi ? h->gs[g][0] : s, sb = multi ? h->gs[g][1] : s, sc = multi ? h->gs[g][2] : s;
+    if (multi) {
+      HIPCHK(hipEventRecord(h->gev[g][0], sm));
+      HIPCHK(hipStreamWaitEvent(sb, h->gev[g][0], 0)); HIPCHK(hipStreamWaitEvent(sc, h->gev[g][0], 0));
+    }
+#define MAYBE_TIMED(strm, cls, units_, call) do { if (timed) TIMED_ON(strm, cls, units_, call); else { call; } } while (0)
+    // the cone workgroups are few (two per CU, long serial phases) and the column waves many: the cone kernel goes first so that its
+    // workgroups are resident when the column kernel floods the wave slots (OMC_COLPROX_FIRST=1 restores the other order)
+    static const bool colprox_first = getenv("OMC_COLPROX_FIRST") != nullptr;
+    if (colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
+    if (w.sub_enable) MAYBE_TIMED(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
+    if (!colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
+    if (h->ws_lpp) MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
+    else MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone(&wg, CONE_CLIP01, h->cone_use_lds, h->cone_lds, sm));
+    MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
+    if (multi) {
+      HIPCHK(hipEventRecord(h->gev[g][1], sb)); HIPCHK(hipEventRecord(h->gev[g][2], sc));
+      HIPCHK(hipStreamWaitEvent(sm, h->gev[g][1], 0)); HIPCHK(hipStreamWaitEvent(sm, h->gev[g][2], 0));
+    }
+    MAYBE_TIMED(sm, OMC_KERNEL_GLOBAL, gact[g], omc_launch_global(&wg, h->glob_use_lds, h->glob_lds, sm));
+    if (with_aa) MAYBE_TIMED(sm, OMC_KERNEL_ACCEL, gact[g], omc_launch_aa(&wg, sm));
+    return 0;
+  };
   while (nactive > 0) {
     ++it;
     const bool is_check = (it % check == 0);
     if (multi && wait_main) HIPCHK(hipEventRecord(h->ev_main, s));
+    const bool use_graph = multi && G == 1 && use_list && nlist <= graph_max && !getenv("OMC_NO_GRAPH");
     for (int g = 0; g < G; ++g) {
       if (gact[g] == 0) continue;
       OmcWS wg = w; wg.b0 = gb0[g]; wg.nB = gnB[g];
       if (use_list && G == 1) { wg.slot_list = h->bslotlist.as<int>(); wg.b0 = 0; wg.nB = nlist; }
-      hipStream_t sm = multi ? h->gs[g][0] : s, sb = multi ? h->gs[g][1] : s, sc = multi ? h->gs[g][2] : s;
-      if (multi) {
-        if (wait_main) HIPCHK(hipStreamWaitEvent(sm, h->ev_main, 0));
-        HIPCHK(hipEventRecord(h->gev[g][0], sm));
-        HIPCHK(hipStreamWaitEvent(sb, h->gev[g][0], 0)); HIPCHK(hipStreamWaitEvent(sc, h->gev[g][0], 0));
+      hipStream_t sm = multi ? h->gs[g][0] : s;
+      if (multi && wait_main) HIPCHK(hipStreamWaitEvent(sm, h->ev_main, 0));
+      if (use_graph) {
+        if (gexec_n != nlist) {      // (re)capture: one graph without and one with the acceleration kernel at its end
+          for (int q = 0; q < 2; ++q) { if (gexec[q]) { (void)hipGraphExecDestroy(gexec[q]); gexec[q] = nullptr; } }
+          for (int q = 0; q < (w.accel ? 2 : 1); ++q) {
+            hipGraph_t gr = nullptr;
+            HIPCHK(hipStreamBeginCapture(sm, hipStreamCaptureModeThreadLocal));
+            int rc = body(g, wg, false, q == 1);
+            hipError_t ce = hipStreamEndCapture(sm, &gr);
+            if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+            HIPCHK(ce);
+            hipError_t ie = hipGraphInstantiate(&gexec[q], gr, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(gr);
+            HIPCHK(ie);
+          }
+          gexec_n = nlist;
+        }
+        const int q = (!is_check && w.accel) ? 1 : 0;
+        HIPCHK(hipGraphLaunch(gexec[q], sm));
+        h->launches[OMC_KERNEL_GLOBAL] += 1; h->units[OMC_KERNEL_GLOBAL] += gact[g];
+      } else {
+        int rc = body(g, wg, true, !is_check && w.accel); if (rc) return rc;
       }
-      TIMED_ON(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
-      if (w.sub_enable) TIMED_ON(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
-      if (h->ws_lpp) TIMED_ON(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
-      else TIMED_ON(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone(&wg, CONE_CLIP01, h->cone_use_lds, h->cone_lds, sm));
-      TIMED_ON(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
-      if (multi) {
-        HIPCHK(hipEventRecord(h->gev[g][1], sb)); HIPCHK(hipEventRecord(h->gev[g][2], sc));
-        HIPCHK(hipStreamWaitEvent(sm, h->gev[g][1], 0)); HIPCHK(hipStreamWaitEvent(sm, h->gev[g][2], 0));
-      }
-      TIMED_ON(sm, OMC_KERNEL_GLOBAL, gact[g], omc_launch_global(&wg, h->glob_use_lds, h->glob_lds, sm));
-      if (!is_check && w.accel) TIMED_ON(sm, OMC_KERNEL_ACCEL, gact[g], omc_launch_aa(&wg, sm));
       if (multi && is_check) { HIPCHK(hipEventRecord(h->gev[g][3], sm)); HIPCHK(hipStreamWaitEvent(s, h->gev[g][3], 0)); }
     }
     wait_main = false;
