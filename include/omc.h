@@ -140,6 +140,14 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
  * Lets one batch try several penalties on the root (autotune) or give children their parent's value. */
 int omc_set_node_rho_scales(omc_instance* h, int B, const double* rho_scale);
 int omc_relax_solve(omc_instance* h);
+/* Asynchronous form of omc_relax_solve: submit returns at once (the solve runs on a worker thread of the library), poll reports
+ * progress (running flag, nodes harvested so far, nodes staged), wait joins and returns the solve's return code (message via
+ * omc_last_error on the waiting thread).  The reference's loop is serial (OMC.jl:700-719); with this the host can prepare the next
+ * batch -- pop, prune (OMC.jl:1220-1244), build children -- while the device relaxes the current one.  One solve in flight per handle;
+ * between submit and wait only omc_relax_poll may be called on the handle. */
+int omc_relax_submit(omc_instance* h);
+int omc_relax_poll(omc_instance* h, int* running, int* nodes_done, int* nodes_total);
+int omc_relax_wait(omc_instance* h);
 int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int* status, int* iters, double* Y,
                     double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x,
                     double* solve_time);

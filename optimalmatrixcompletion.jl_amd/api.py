@@ -107,6 +107,18 @@ class Engine:
     def solve(self):
         _lib.check(self._lib.omc_relax_solve(self._h))
 
+    def submit(self):
+        """Asynchronous solve of the staged batch: returns at once; poll() / wait() follow (omc_relax_submit)."""
+        _lib.check(self._lib.omc_relax_submit(self._h))
+
+    def poll(self):
+        r = np.zeros(3, np.int32)
+        _lib.check(self._lib.omc_relax_poll(self._h, _lib.ptr(r[0:1]), _lib.ptr(r[1:2]), _lib.ptr(r[2:3])))
+        return dict(running=bool(r[0]), nodes_done=int(r[1]), nodes_total=int(r[2]))
+
+    def wait(self):
+        _lib.check(self._lib.omc_relax_wait(self._h))
+
     def fetch(self, want_Y=True, want_X=True, want_Theta=False):
         B, n, m, k = self._B, self.n, self.m, self.k
         obj = np.zeros(B); lb = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)

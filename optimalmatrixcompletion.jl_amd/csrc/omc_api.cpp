@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 #include "omc.h"
 #include "omc_device.h"
@@ -79,6 +81,7 @@ struct omc_instance {
   bool staged = false;
   int cone_use_lds = 0, glob_use_lds = 0, small_use_lds = 0; size_t cone_lds = 0, glob_lds = 0, small_lds = 0;
   double last_solve_seconds = 0; long long total_sweeps = 0; int last_iters_total = 0;
+  std::thread worker; std::atomic<int> worker_running{0}, nodes_done{0}; int worker_rc = 0; std::string worker_err;
   void* comm = nullptr; int comm_rank = 0, comm_world = 1; DevBuf bcomm, amobj; int amobj_B = 0;
   std::vector<double> rho_scale_per_node; DevBuf brho, brhon, blamD, bslotint, boY, boU, boal, bobx, boscal, boint;
   int Btot = 0;
@@ -194,6 +197,7 @@ int omc_instance_create_bits(int n, int m, int k, const double* A, const uint64_
 
 void omc_instance_destroy(omc_instance* h) {
   if (!h) return;
+  if (h->worker.joinable()) h->worker.join();
   (void)hipSetDevice(h->device);
   (void)omc_comm_destroy(h);
   h->bcomm.release(); h->amobj.release();
@@ -590,7 +594,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       w.sep_done = (w.sub_enable && !getenv("OMC_NO_SEP_SUB")) ? h->bsubIC.as<int>() + 2 * sB : nullptr;   // opt-in: measured no gain (the eigenvalues are not what the check spends its time on) and fewer rigorous samples of the bound
     }
     h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8 + (size_t)h->nnz * 4 + 16;   // n*m >= n*n: the region also stages Lambda
-    h->glob_use_lds = h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS;   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
+    h->glob_use_lds = (h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS) && !getenv("OMC_GLOBAL_NOLDS");   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
     if (!h->glob_use_lds) {
       w.glob_scratch_stride = h->glob_lds / 8 + 8;
       ENS(h->bglob, sB * w.glob_scratch_stride * 8);
@@ -817,7 +821,7 @@ int omc_relax_solve(omc_instance* h) {
         omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, s);           // separation vector (OMC.jl:2466-2477)
         omc_launch_harvest(&w, s);
       });
-      harvested += nfin;
+      harvested += nfin; h->nodes_done.store(harvested);
       int ninit = 0;
       for (int b = 0; b < S; ++b) {
         if (!fin[b]) continue;
@@ -861,6 +865,38 @@ int omc_relax_solve(omc_instance* h) {
   h->last_iters_total = it;
   (void)harvested;
   return 0;
+}
+
+// ---- asynchronous boundary: the solve runs on a worker thread of the library, the caller (the Julia task that owns the queue) keeps
+// working -- popping, pruning, building the next batch -- and polls.  One solve in flight per handle; no other call on the handle
+// except omc_relax_poll until omc_relax_wait has returned.
+int omc_relax_submit(omc_instance* h) {
+  if (!h || !h->staged) return fail(OMC_ERR_ARGUMENT, "omc_relax_submit: nothing staged");
+  if (h->worker.joinable()) return fail(OMC_ERR_ARGUMENT, "omc_relax_submit: a solve is already in flight (call omc_relax_wait first)");
+  h->nodes_done.store(0); h->worker_running.store(1); h->worker_rc = 0; h->worker_err.clear();
+  h->worker = std::thread([h]() {
+    const int rc = omc_relax_solve(h);
+    h->worker_rc = rc;
+    if (rc) h->worker_err = g_err;        // g_err is thread-local: hand the message to the thread that will call omc_relax_wait
+    h->worker_running.store(0);
+  });
+  return 0;
+}
+
+int omc_relax_poll(omc_instance* h, int* running, int* nodes_done, int* nodes_total) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (running) *running = h->worker_running.load();
+  if (nodes_done) *nodes_done = h->nodes_done.load();
+  if (nodes_total) *nodes_total = h->Btot;
+  return 0;
+}
+
+int omc_relax_wait(omc_instance* h) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (!h->worker.joinable()) return fail(OMC_ERR_ARGUMENT, "omc_relax_wait: no solve in flight");
+  h->worker.join();
+  if (h->worker_rc) g_err = h->worker_err;
+  return h->worker_rc;
 }
 
 int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int* status, int* iters, double* Y,

@@ -726,3 +726,35 @@ def test_rccl_communicator_single_rank(have_gpu, omc):
     with pytest.raises(omc.OmcError):
         eng.comm_init(0, 1, omc.Engine.comm_unique_id())                  # already initialised
     eng.close()
+
+
+def test_asynchronous_submit_poll_wait(have_gpu, omc, orc):
+    """omc_relax_submit / poll / wait: the solve runs on the library's worker thread while the host keeps working; results are those of
+    the blocking call."""
+    import time
+    A, mask = orc.make_instance(24, 28, 1, seed=12, kind="lowrank", n_indices=int(0.4 * 24 * 28))
+    inst = orc.Instance(A, mask, GAMMA, 1)
+    nodes = oracle_path(orc, inst, "linear", 3, 4.0, seed=3)
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    P = omc.default_params(rho_scale=4.0, slots=2)
+    ref = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P)
+    eng.stage(nodes, "linear", P)
+    eng.submit()
+    with pytest.raises(omc.OmcError):
+        eng.submit()                                   # one solve in flight per handle
+    seen = []; host_work = 0
+    while True:
+        st = eng.poll(); seen.append(st["nodes_done"])
+        host_work += int(np.linalg.norm(np.ones(64)))  # the host thread is free
+        if not st["running"]:
+            break
+        time.sleep(0.002)
+    eng.wait()
+    with pytest.raises(omc.OmcError):
+        eng.wait()                                     # nothing in flight any more
+    out = eng.fetch()
+    assert seen == sorted(seen) and eng.poll()["nodes_done"] == len(nodes) == eng.poll()["nodes_total"]
+    for a, b in zip(out, ref):
+        assert a["status_code"] == b["status_code"] and a["iters"] == b["iters"]
+        assert a["objective"] == b["objective"] and a["dual_bound"] == b["dual_bound"]
+    eng.close()
