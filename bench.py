@@ -48,6 +48,10 @@ def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher: start the N ranks as children (nothing in this process has touched the GPU,
     and the children are fresh interpreters -- never an exec of a process that initialised HIP) and exit with their code."""
     import socket
+    import torch
+    have = torch.cuda.device_count()          # counts devices without initialising the GPU in this (parent) process
+    if have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(args.gpus):
@@ -55,8 +59,18 @@ def spawn_ranks(args):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    live = list(procs)
+    while live:                                 # a rank that dies must not leave the others waiting in a collective
+        time.sleep(0.5)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = rc or r
+                for q in live:
+                    q.terminate()
     sys.exit(rc)
 
 
@@ -125,7 +139,12 @@ def main():
     A, mask, gamma, cfg = data.config_instance(args.config, seed=0)
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
     eng = omc_amd.Engine(A, mask, gamma, k, device=local)
-    if world > 1:   # the library's own RCCL communicator (C ABI); torch.distributed only carries the 128-byte id to the ranks
+    use_comm = world > 1 or bool(os.environ.get("OMC_BENCH_FORCE_COMM"))     # the env var exercises the exchange path with a world of one
+    if use_comm:    # the library's own RCCL communicator (C ABI); torch.distributed only carries the 128-byte id to the ranks
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=0, world_size=1)
         box = [eng.comm_unique_id().tobytes() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         eng.comm_init(rank, world, np.frombuffer(box[0], dtype=np.uint8))
@@ -150,7 +169,7 @@ def main():
         eng.solve()
         out = eng.fetch(want_Y=False, want_X=False)
         ub = min(o["objective"] for o in out); lb = min(o["dual_bound"] for o in out)
-        if world > 1:
+        if use_comm:
             ub, lb, _ = eng.allreduce_bounds(ub, lb)
         return (ub, lb), out
 
@@ -266,7 +285,7 @@ def main():
             "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"),
         }))
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

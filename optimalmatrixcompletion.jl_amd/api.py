@@ -231,8 +231,9 @@ class Engine:
         _lib.check(self._lib.omc_altmin_batch(self._h, B, CUT_TYPES[disjunctive_cuts_type], int(reference_quirk_q1), _lib.ptr(L),
                                               _lib.ptr(cx), _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(U0), float(eps), int(max_iters),
                                               float(time_limit), _lib.ptr(U), _lib.ptr(V), _lib.ptr(cv), _lib.ptr(ni), _lib.ptr(obj), _lib.ptr(tm)))
-        mo = np.zeros(B)
-        _lib.check(self._lib.omc_altmin_master_objectives(self._h, B, _lib.ptr(mo)))
+        mo = np.full(B, np.nan)
+        if time_limit > 0:
+            _lib.check(self._lib.omc_altmin_master_objectives(self._h, B, _lib.ptr(mo)))
         # master_objective = evaluate_objective(U V) (OMC.jl:920-927), evaluated on the device from the factors
         return [dict(converged=bool(cv[b]), U=U[b].reshape((n, k), order="F"), V=V[b].reshape((k, m), order="F"),
                      solve_time=float(tm[b]), n_iters=int(ni[b]), max_iters=max_iters, objectives=list(obj[b, :ni[b] - (0 if cv[b] or ni[b] == 0 or not np.isnan(obj[b, ni[b] - 1]) else 1)]),

@@ -138,6 +138,7 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   if (device < 0 || device >= ndev) return fail(OMC_ERR_ARGUMENT, "device index out of range");
   HIPCHK(hipSetDevice(device));
   omc_instance* h = new omc_instance();
+  struct Guard { omc_instance*& p; ~Guard() { if (p) omc_instance_destroy(p); } } guard{h};     // every early return below frees the handle
   h->n = n; h->m = m; h->k = k; h->gamma = gamma; h->device = device;
   h->A.assign(A, A + (size_t)n * m);
   h->mask.resize((size_t)n * m);
@@ -168,21 +169,22 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   }
   HIPCHK(hipStreamCreate(&h->stream));
   int rc = 0;
-  if ((rc = upload(h->drow_ptr, h->row_ptr.data(), sizeof(int) * (n + 1), h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->drow_idx, h->row_idx.data(), sizeof(int) * h->nnz_rows(), h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->drow_val, h->row_val.data(), sizeof(double) * h->nnz_rows(), h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->dA, h->A.data(), sizeof(double) * n * m, h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->dmask, h->mask.data(), (size_t)n * m, h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->dcol_ptr, h->col_ptr.data(), sizeof(int) * (m + 1), h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->dcol_idx, h->col_idx.data(), sizeof(int) * h->nnz, h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->dcol_val, h->col_val.data(), sizeof(double) * h->nnz, h->stream))) { delete h; return rc; }
-  if ((rc = upload(h->dNcnt, h->Ncnt.data(), sizeof(double) * n * n, h->stream))) { delete h; return rc; }
+  if ((rc = upload(h->drow_ptr, h->row_ptr.data(), sizeof(int) * (n + 1), h->stream))) return rc;
+  if ((rc = upload(h->drow_idx, h->row_idx.data(), sizeof(int) * h->nnz_rows(), h->stream))) return rc;
+  if ((rc = upload(h->drow_val, h->row_val.data(), sizeof(double) * h->nnz_rows(), h->stream))) return rc;
+  if ((rc = upload(h->dA, h->A.data(), sizeof(double) * n * m, h->stream))) return rc;
+  if ((rc = upload(h->dmask, h->mask.data(), (size_t)n * m, h->stream))) return rc;
+  if ((rc = upload(h->dcol_ptr, h->col_ptr.data(), sizeof(int) * (m + 1), h->stream))) return rc;
+  if ((rc = upload(h->dcol_idx, h->col_idx.data(), sizeof(int) * h->nnz, h->stream))) return rc;
+  if ((rc = upload(h->dcol_val, h->col_val.data(), sizeof(double) * h->nnz, h->stream))) return rc;
+  if ((rc = upload(h->dNcnt, h->Ncnt.data(), sizeof(double) * n * n, h->stream))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   int lrc = omc_set_max_lds();
-  if (lrc) { delete h; return fail(lrc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); }
-  { int arc = omc_altmin_set_lds(); if (arc) { delete h; return fail(5000 + arc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the altmin kernel"); } }
+  if (lrc) return fail(lrc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  { int arc = omc_altmin_set_lds(); if (arc) return fail(5000 + arc, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the altmin kernel"); }
   omc_relax_params_default(&h->params);
   *out = h;
+  h = nullptr;          // released to the caller (the guard holds a reference to this pointer)
   return 0;
 }
 
@@ -1005,8 +1007,15 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
                      const double* cut_Uhat, const int8_t* cut_dir, const double* U_initial, double eps, int max_iters,
                      double time_limit, double* U, double* V, int* converged, int* n_iters, double* objectives,
                      double* solve_time) {
-  (void)time_limit;
   if (!h || !U_initial || !U || !V) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (!(time_limit > 0.0)) {      // OMC.jl:2186-2189: the loop condition fails at once -- nothing is solved (a launch runs <= max_iters iterations in milliseconds, so this is the only case in which the limit can bind)
+    const size_t nk = (size_t)h->n * h->k, mk = (size_t)h->m * h->k;
+    for (int b = 0; b < B; ++b) { if (converged) converged[b] = 0; if (n_iters) n_iters[b] = 0; if (solve_time) solve_time[b] = 0.0; }
+    memset(U, 0, sizeof(double) * nk * B); memset(V, 0, sizeof(double) * mk * B);
+    if (objectives) for (size_t e = 0; e < (size_t)B * max_iters; ++e) objectives[e] = NAN;
+    h->amobj_B = 0;
+    return 0;
+  }
   if (B <= 0 || max_iters <= 0) return fail(OMC_ERR_ARGUMENT, "B and max_iters must be positive");
   if (cut_type != OMC_CUT_LINEAR && cut_type != OMC_CUT_LINEAR2 && cut_type != OMC_CUT_LINEAR3)
     return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type (OMC.jl:1456-1462)");

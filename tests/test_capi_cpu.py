@@ -113,3 +113,13 @@ def test_shor_and_altmin_argument_checks_without_a_handle(omc):
     assert lib.omc_shor_last_stats(None, None, None) == -3
     assert lib.omc_altmin_batch(None, 1, 0, 1, None, None, None, None, None, 1e-5, 10, 1.0, None, None, None, None, None, None) == -3
     assert b"NULL" in lib.omc_last_error() or b"handle" in lib.omc_last_error()
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` spawns its ranks itself; asking for more ranks than there are GPUs must fail at once, not hang in a collective."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) are visible" in (r.stderr + r.stdout)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)
