@@ -282,3 +282,54 @@ def test_ustep_dual_newton_matches_slsqp(orc):
         assert i1["kkt_residual"] <= 1e-9 and (((U1 @ W.T) ** 2).sum(0) - rad).max() <= 1e-9
         if i2["slsqp_status"] == 0:
             assert o1 == pytest.approx(o2, rel=1e-7) and o1 <= o2 + 1e-9 * max(1.0, abs(o2))
+
+
+@pytest.mark.parametrize("seed,cut_type,dirs", [(0, "linear", ["right"]), (1, "linear", ["left"]), (2, "linear2", ["right"]), (3, "linear3", ["left"]), (4, "linear2", ["middle"])])
+def test_dual_bound_against_an_independent_solve_on_a_cut_node(seed, cut_type, dirs):
+    """Validity of the certificate on a node WITH a cut, checked by a different method: the node program restricted to its (Y, U) form
+    (X, Theta eliminated in closed form, KAT-4) is solved by scipy SLSQP over the factorisation Y = U U' + R R' (so [Y U; U' I] >= 0 holds
+    by construction), with I - Y >= 0 as an eigenvalue constraint and the cut rows of OMC.jl:1580-1683 written out by hand.  Every point
+    SLSQP visits is feasible for the relaxation, so its value can never fall below the oracle's dual bound; at convergence it matches
+    the oracle's objective."""
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(seed)
+    n, m, k = 5, 6, 1
+    A, mask = orc.make_instance(n, m, k, seed=40 + seed, kind="lowrank", n_indices=18, noise=0.3)
+    inst = orc.Instance(A, mask, GAMMA, k)
+    root = orc.sdp_relaxation(inst, params=orc.RelaxParams(rho_scale=8.0), want_certificate=False)
+    x, _ = orc.breakpoint_vector(root["Y"], root["U"])
+    cut = (x, root["U"].copy(), dirs)
+    r = orc.sdp_relaxation(inst, [cut], cut_type, params=orc.RelaxParams(rho_scale=8.0))
+    assert r["termination_status"] in (orc.OMC_OPTIMAL, orc.OMC_SLOW_PROGRESS)      # the `middle` piece has no Slater point when |v-hat| is small: bound valid, not certified
+    vhat = float(root["U"][:, 0] @ x)
+    lo, hi, sl, ic = orc.cut_piece(cut_type, dirs[0], vhat)
+    iu = np.tril_indices(n)
+
+    def unpack(z):
+        u = z[:n]; R = np.zeros((n, n)); R[iu] = z[n:]
+        return u, np.outer(u, u) + R @ R.T
+
+    def fobj(z):
+        _, Y = unpack(z)
+        return inst.f_value(Y)
+
+    cons = [
+        dict(type="ineq", fun=lambda z: 1.0 - np.trace(unpack(z)[1])),                                  # tr Y <= k      (OMC.jl:1558)
+        dict(type="ineq", fun=lambda z: 1.0 - np.linalg.eigvalsh(unpack(z)[1])[-1]),                   # I - Y >= 0     (OMC.jl:1556)
+        dict(type="ineq", fun=lambda z: 1.0 - float(z[:n] @ z[:n])),                                   # ||U_1|| <= 1   (OMC.jl:1831-1835)
+        dict(type="ineq", fun=lambda z: z[n - 1]),                                                    # U[n, 1] >= 0   (OMC.jl:1442-1449)
+        dict(type="ineq", fun=lambda z: float(x @ z[:n]) - lo), dict(type="ineq", fun=lambda z: hi - float(x @ z[:n])),   # bounds on v
+        dict(type="ineq", fun=lambda z: sl * float(x @ z[:n]) + ic - float(x @ unpack(z)[1] @ x)),    # x'Yx <= g(v)   (OMC.jl:1680-1683)
+    ]
+    best = np.inf
+    for trial in range(6):
+        u0 = r["U"][:, 0] + 0.05 * rng.standard_normal(n) if trial == 0 else 0.3 * rng.standard_normal(n)
+        z0 = np.concatenate([u0, 0.2 * rng.standard_normal(len(iu[0]))])
+        res = minimize(fobj, z0, constraints=cons, bounds=[(-1, 1)] * n + [(None, None)] * len(iu[0]), method="SLSQP", options=dict(ftol=1e-13, maxiter=500))
+        feas = all(c["fun"](res.x) >= -1e-8 for c in cons)
+        if feas:
+            assert r["dual_bound"] <= res.fun + 1e-7 * abs(res.fun)          # a feasible value can never undercut a valid bound
+            best = min(best, res.fun)
+    assert np.isfinite(best)
+    if r["termination_status"] == orc.OMC_OPTIMAL:
+        assert r["objective"] == pytest.approx(best, rel=2e-5)                # and the independent optimum is the oracle's
