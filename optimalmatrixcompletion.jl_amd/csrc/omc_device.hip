@@ -1261,7 +1261,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   };
 
   int steps = 0, ok = 0, fail = 0, nrr = 0;
-  const int qmax = w.sub_qmax, chunk = w.sub_chunk;
+  const int qmax = (MODE == 2) ? 4 * w.sub_qmax : w.sub_qmax, chunk = w.sub_chunk;      // MODE 2: the alternative is a cold eigendecomposition
   const bool prof = (w.sub_debug == 2) && b == 0;
   long long tprev = prof ? __builtin_amdgcn_s_memtime() : 0;
 #define SUBSTAMP(slot) do { if (prof) { __syncthreads(); if (tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); w.stamps[slot] += (double)(t_ - tprev); tprev = t_; } } } while (0)
