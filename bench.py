@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--accel", type=int, default=int(os.environ.get("OMC_BENCH_ACCEL", 0)), help="1: Anderson acceleration of the ADMM map (library default 0)")
     ap.add_argument("--cpu-nodes", type=int, default=4, help="nodes relaxed by the CPU oracle per leg of cpu_baseline (rank 0, N=1 only)")
+    ap.add_argument("--frontier-file", default=None, help="N=1: cache of the tuned penalty scale and the frontier (written when absent, read when present) so that a "
+                    "profiled run launches the kernels of the timed steps only (tools/prof_round2.sh)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip latency_b1 / branching / time_to_gap / cpu_baseline (rank 0, N=1 only)")
     return ap.parse_args()
 
@@ -148,11 +150,25 @@ def main():
         box = [eng.comm_unique_id().tobytes() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         eng.comm_init(rank, world, np.frombuffer(box[0], dtype=np.uint8))
-    rho_scale, tune_log = bnb.autotune_rho_scale(eng, cfg["cut_type"])
-    P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel)
-    # every rank builds the same depth-d frontier (deterministic), keeps its round-robin share and expands THOSE subtrees until it
-    # holds 2^d nodes again: distinct work per rank, identical amount of it
-    nodes, _ = bnb.expand_frontier(eng, args.depth, cfg["cut_type"], params=P)
+    cache = args.frontier_file if world == 1 else None
+    if cache and os.path.exists(cache):
+        import pickle
+        with open(cache, "rb") as f:                 # a file this script wrote itself
+            saved = pickle.load(f)
+        if saved["key"] != (args.config, args.depth):
+            sys.exit(f"bench.py: {cache} holds config/depth {saved['key']}")
+        rho_scale, tune_log, nodes = saved["rho_scale"], saved["tune_log"], saved["nodes"]
+        P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel)
+    else:
+        rho_scale, tune_log = bnb.autotune_rho_scale(eng, cfg["cut_type"])
+        P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel)
+        # every rank builds the same depth-d frontier (deterministic), keeps its round-robin share and expands THOSE subtrees until it
+        # holds 2^d nodes again: distinct work per rank, identical amount of it
+        nodes, _ = bnb.expand_frontier(eng, args.depth, cfg["cut_type"], params=P)
+        if cache:
+            import pickle
+            with open(cache, "wb") as f:
+                pickle.dump(dict(key=(args.config, args.depth), rho_scale=rho_scale, tune_log=tune_log, nodes=nodes), f)
     B = len(nodes)
     if world > 1:
         mine = bnb.shard_nodes(nodes, rank, world)

@@ -454,7 +454,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.Xs = h->bXs.as<double>(); w.sub_theta = h->bsubS.as<double>(); w.trM = h->bsubS.as<double>() + sB * 16;
     w.sub_on = h->bsubI.as<int>(); w.cone_done = h->bsubI.as<int>() + sB; w.sub_stat = h->bsubI.as<int>() + 2 * sB; w.sub_wait = h->bsubI.as<int>() + 10 * sB; w.sub_nfail = h->bsubI.as<int>() + 11 * sB;
     w.sub_qmax = getenv("OMC_SUB_QMAX") ? atoi(getenv("OMC_SUB_QMAX")) : 24;
-    w.sub_chunk = getenv("OMC_SUB_CHUNK") ? atoi(getenv("OMC_SUB_CHUNK")) : 4;
+    w.sub_chunk = getenv("OMC_SUB_CHUNK") ? atoi(getenv("OMC_SUB_CHUNK")) : 3;
     w.sub_tol = getenv("OMC_SUB_TOL") ? atof(getenv("OMC_SUB_TOL")) : 1e-10;
     w.sub_adapt = getenv("OMC_SUB_ADAPT") ? atof(getenv("OMC_SUB_ADAPT")) : 1e-3;
     w.sub_debug = getenv("OMC_SUB_DEBUG") ? atoi(getenv("OMC_SUB_DEBUG")) : 0;
@@ -595,7 +595,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       w.cert_enable = (w.sub_enable && w.MbufC && getenv("OMC_CERT_SUB")) ? 1 : 0;
       w.sep_done = (w.sub_enable && !getenv("OMC_NO_SEP_SUB")) ? h->bsubIC.as<int>() + 2 * sB : nullptr;   // opt-in: measured no gain (the eigenvalues are not what the check spends its time on) and fewer rigorous samples of the bound
     }
-    h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 2 * Rmax + 8) * 8 + (size_t)h->nnz * 4 + 16;   // n*m >= n*n: the region also stages Lambda
+    h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 3 * Rmax + 8 + 16 * (size_t)n) * 8 + 16;   // n*m >= n*n: the region also stages Lambda; 16 = GL_XS staged cut vectors
     h->glob_use_lds = (h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS) && !getenv("OMC_GLOBAL_NOLDS");   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
     if (!h->glob_use_lds) {
       w.glob_scratch_stride = h->glob_lds / 8 + 8;

@@ -1582,6 +1582,61 @@ __device__ __forceinline__ void mfma_LLt(const double* L, int n, int m, StoreF s
   }
 }
 
+// The same product with L staged in LDS and the tiles kept in registers (wave w owns the lower-triangle tiles w, w + nw, ..: at most
+// MAXT of them), because the LDS region of L is overwritten by the target before the product is added to it (k_global).
+template <int MAXT>
+__device__ __forceinline__ void mfma_LLt_tiles(const double* L, int n, int m, double4v (&accT)[MAXT]) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int nt = (n + 15) >> 4, ntile = nt * (nt + 1) / 2;
+#pragma unroll
+  for (int u = 0; u < MAXT; ++u) {
+    const int tile = wv + u * nw;
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    if (tile < ntile) {                               // wave-uniform
+      int ti = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+      while (ti * (ti + 1) / 2 > tile) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+      const int tj = tile - ti * (ti + 1) / 2;
+      const int ia = (ti << 4) + li, jb = (tj << 4) + li;
+      const bool va = ia < n, vb = jb < n;
+      const double* La = L + (va ? ia : 0);
+      const double* Lb = L + (vb ? jb : 0);
+      const int m4 = m & ~3;
+      int k0 = 0;
+      for (; k0 < m4; k0 += 4) {
+        const double a = La[(size_t)(k0 + lk) * n], bv = Lb[(size_t)(k0 + lk) * n];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va ? a : 0.0, vb ? bv : 0.0, acc, 0, 0, 0);
+      }
+      if (k0 < m) {
+        const int kk = k0 + lk; const bool vk = kk < m; const int kc = vk ? kk : 0;
+        const double a = La[(size_t)kc * n], bv = Lb[(size_t)kc * n];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((va && vk) ? a : 0.0, (vb && vk) ? bv : 0.0, acc, 0, 0, 0);
+      }
+    }
+    accT[u] = acc;
+  }
+}
+template <int MAXT, class StoreF>
+__device__ __forceinline__ void mfma_LLt_emit(int n, const double4v (&accT)[MAXT], StoreF store) {
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int nt = (n + 15) >> 4, ntile = nt * (nt + 1) / 2;
+#pragma unroll
+  for (int u = 0; u < MAXT; ++u) {
+    const int tile = wv + u * nw;
+    if (tile < ntile) {
+      int ti = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+      while (ti * (ti + 1) / 2 > tile) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+      const int tj = tile - ti * (ti + 1) / 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = (ti << 4) + lk + 4 * r, j = (tj << 4) + li;
+        if (i < n && j < n && i >= j) store(i, j, accT[u][r]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_small: the small cone  [S Vt; Vt' T] >= 0,  S = Q'(Y - D3)Q (r x r),  Vt - D3V (r x k),  T = I - D3T.
 //   mode SMALL_PROJ   : P3 = P_+(M3);  Q3 = P3 - M3 (>= 0: the multiplier direction);
@@ -1787,6 +1842,7 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
 //   mu = argmin 1/2 mu'G1 mu - c'mu, mu >= 0 (c = A t - b) ;  lam = rho mu
 //   Yn = tY - A_Y' mu / wY1 ;  Vn = tV - Q'(A_U' mu)/2
 // ---------------------------------------------------------------------------------------------------------
+#define GL_XS 16   // cut vectors staged per pass of k_global (one MFMA column block)
 template <bool USE_LDS>
 __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   extern __shared__ double smem[];
@@ -1819,32 +1875,20 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const double rho = w.rho_b[b], rho_f = rho * w.rho_f_ratio, rx = w.relax, g = w.gamma;
   STAMP_BEGIN();
   DIAG_T0();
-  // 1. gamma/2 * Lambda Lambda', output-stationary and deterministic.  LDS path: the dense column-major copy of Lambda
-  //    (written by k_colprox, zero where a row is not observed) and the CSR column lists are staged in LDS -- in the
-  //    region that holds the target afterwards -- and every thread keeps its <= GL_MAXOUT sums in registers.
-  constexpr int GL_MAXOUT = 32;
-  double accLL[GL_MAXOUT];
+  // 1. gamma/2 * Lambda Lambda' on the matrix cores (deterministic: one wave owns a tile).  LDS path: the dense column-major copy of
+  //    Lambda (written by k_colprox, zero where a row is not observed) is staged in LDS -- in the region that holds the target
+  //    afterwards -- and every wave keeps its <= GL_MAXT lower-triangle tiles in registers.  (The walk over the CSR lists that this
+  //    replaces did a fifth of the flops and took 41 us of the 108 us of this kernel at n = m = 100.)
+  constexpr int GL_MAXT = 6;                             // tiles per wave: 45 lower-triangle tiles (n <= 144) over 8 waves
+  double4v accLL[GL_MAXT];
   const double* lamD = w.lamD + (size_t)b * m * n;
-  const bool ll_in_lds = USE_LDS && (n * n <= GL_MAXOUT * T);
+  const int nt16 = (n + 15) >> 4;
+  const bool ll_in_lds = USE_LDS && (nt16 * (nt16 + 1) / 2 <= GL_MAXT * (T >> 6));
   if (ll_in_lds) {
     double* LamS = tY;                                   // n*m doubles (region sized max(n*n, n*m) by the host)
-    int* ridx = (int*)(mu + w.Rmax);                     // nnz ints
     for (int e = tid; e < n * m; e += T) LamS[e] = lamD[e];
-    for (int e = tid; e < w.nnz; e += T) ridx[e] = w.row_idx[e];
     __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < GL_MAXOUT; ++kk) {
-      const int e = tid + kk * T;
-      double acc = 0.0;
-      if (e < n * n) {
-        const int i2 = e % n, i = e / n;
-        for (int p = w.row_ptr[i]; p < w.row_ptr[i + 1]; ++p) {
-          const double* lj = LamS + (size_t)ridx[p] * n;
-          acc += lj[i] * lj[i2];
-        }
-      }
-      accLL[kk] = acc;
-    }
+    mfma_LLt_tiles<GL_MAXT>(LamS, n, m, accLL);
     __syncthreads();
   }
   STAMP(8);
@@ -1860,11 +1904,11 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   for (int e = tid; e < R; e += T) mu[e] = lam[e] / rho;
   __syncthreads();
   if (ll_in_lds) {
-#pragma unroll
-    for (int kk = 0; kk < GL_MAXOUT; ++kk) {
-      const int e = tid + kk * T;
-      if (e < n * n) { const int i2 = e % n, i = e / n; tY[(size_t)i * n + i2] += 0.5 * g * accLL[kk]; }
-    }
+    mfma_LLt_emit<GL_MAXT>(n, accLL, [&](int i, int j, double v) {
+      const double t = 0.5 * g * v;
+      tY[(size_t)j * n + i] += t;
+      if (i != j) tY[(size_t)i * n + j] += t;
+    });
   } else {
     // large orders: Lambda Lambda' as a dense MFMA product of the zero-padded copy (deterministic: one wave owns a tile)
     mfma_LLt(lamD, n, m, [&](int i, int j, double v) {
@@ -1883,9 +1927,61 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   }
   __syncthreads();
   STAMP(9);
-  // 3. c = A t - b
+  // 3. c = A t - b.  The quadratic forms x' tY x of the cut rows come from the matrix cores: the cut vectors of up to GL_XS rows are
+  //    staged as the columns of X, wave w forms the 16-row tiles w, w + nw, .. of tY X and reduces x_i (tY X)_i over its rows; the
+  //    waves' partial sums are added in a fixed order.
   const double* cutx = w.cutx + (size_t)nb * w.Lmax * n;
-  {   // one WAVE per row (wave-level reductions, no workgroup barrier per row); a cut row is x'(tY x) with lane = row index
+  double* xs = mu + w.Rmax;                              // GL_XS * n: staged cut vectors
+  double* qrow = xs + (size_t)GL_XS * n;                 // Rmax: x' tY x of the cut rows
+  __shared__ int s_crow[GL_XS]; __shared__ int s_nc, s_rnext; __shared__ double s_qp[8][GL_XS];   // 512 threads = 8 waves
+  if (tid == 0) s_rnext = 0;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      int c = 0, rr = s_rnext;
+      for (; rr < R && c < GL_XS; ++rr) if (w.rkind[(size_t)nb * w.Rmax + rr] == ROW_CUT) s_crow[c++] = rr;
+      s_nc = c; s_rnext = rr;
+    }
+    __syncthreads();
+    const int nc = s_nc, rnext = s_rnext;
+    if (nc == 0) break;
+    for (int e = tid; e < nc * n; e += T) { const int c = e / n, i = e - c * n; xs[e] = cutx[(size_t)w.rcut[(size_t)nb * w.Rmax + s_crow[c]] * n + i]; }
+    __syncthreads();
+    {
+      const int wv_ = tid >> 6, lane_ = tid & 63, nw_ = T >> 6, li = lane_ & 15, lk = lane_ >> 4;
+      const bool vc = li < nc;
+      const double* xc = xs + (size_t)(vc ? li : 0) * n;
+      double qsum = 0.0;
+      for (int ti = wv_; ti < nt16; ti += nw_) {
+        const int ia = (ti << 4) + li; const bool va = ia < n;
+        const double* Ta = tY + (va ? ia : 0);
+        double4v acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < n; k0 += 4) {
+          const int kk = k0 + lk; const bool vk = kk < n; const int kc = vk ? kk : 0;
+          const double a = Ta[(size_t)kc * n], bv = xc[kc];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64((va && vk) ? a : 0.0, (vc && vk) ? bv : 0.0, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int i = (ti << 4) + lk + 4 * r4;
+          const double xv = xc[(i < n) ? i : 0];
+          qsum += (vc && i < n) ? xv * acc[r4] : 0.0;
+        }
+      }
+      qsum += __shfl_xor(qsum, 16, WAVE);
+      qsum += __shfl_xor(qsum, 32, WAVE);
+      if (lk == 0) s_qp[wv_][li] = qsum;
+    }
+    __syncthreads();
+    if (tid < nc) {
+      double q = 0.0;
+      for (int v = 0; v < (T >> 6); ++v) q += s_qp[v][tid];
+      qrow[s_crow[tid]] = q;
+    }
+    if (rnext >= R) break;
+  }
+  __syncthreads();
+  {   // one WAVE per row (wave-level reductions, no workgroup barrier per row)
     const int wv_ = tid >> 6, lane_ = tid & 63, nw_ = T >> 6;
     for (int rr = wv_; rr < R; rr += nw_) {
       const int kind = w.rkind[(size_t)nb * w.Rmax + rr];
@@ -1897,13 +1993,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
       } else {
         const double* x = cutx + (size_t)w.rcut[(size_t)nb * w.Rmax + rr] * n;
         const double* cf = w.rcoef + ((size_t)nb * w.Rmax + rr) * k;
-        if (kind == ROW_CUT) {
-          for (int i = lane_; i < n; i += WAVE) {
-            double s2 = 0.0;
-            for (int j = 0; j < n; ++j) s2 += x[j] * tY[(size_t)j * n + i];
-            acc += x[i] * s2;
-          }
-        }
+        if (kind == ROW_CUT && lane_ == 0) acc = qrow[rr];
         for (int j = 0; j < k; ++j) {
           const double cj = cf[j];
           if (cj != 0.0) for (int i = lane_; i < n; i += WAVE) acc += cj * x[i] * tU[(size_t)j * n + i];
@@ -1971,10 +2061,14 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     s_nact = c2; s_trace_mu = tm;
   }
   __syncthreads();
+  const int nact = s_nact, nstg = (nact < GL_XS) ? nact : GL_XS;      // the first GL_XS active cut vectors are read from LDS
+  for (int e = tid; e < nstg * n; e += T) { const int a = e / n, i = e - a * n; xs[e] = cutx[(size_t)s_act[a] * n + i]; }
+  __syncthreads();
   for (int e = tid; e < n * n; e += T) {
     const int i = e % n, j = e / n;
     double corr = (i == j) ? s_trace_mu : 0.0;
-    for (int a = 0; a < s_nact; ++a) { const double* x = cutx + (size_t)s_act[a] * n; corr += s_mu[a] * (x[i] * x[j]); }   // (x_i x_j) first: exactly symmetric in (i, j)
+    for (int a = 0; a < nstg; ++a) { const double* x = xs + (size_t)a * n; corr += s_mu[a] * (x[i] * x[j]); }             // (x_i x_j) first: exactly symmetric in (i, j)
+    for (int a = nstg; a < nact; ++a) { const double* x = cutx + (size_t)s_act[a] * n; corr += s_mu[a] * (x[i] * x[j]); }
     const size_t a1 = (size_t)j * n + i, a2 = (size_t)i * n + j;
     const double t = 0.5 * (tY[a1] + tY[a2]);
     const double yn = t - corr / w.wY1[a1];

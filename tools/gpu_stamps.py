@@ -8,7 +8,7 @@ _lib._lib = None
 A, mask, gamma, c = omc_amd.pkg.data.config_instance(2, seed=0)
 eng = omc_amd.Engine(A, mask, gamma, c["k"])
 P = omc_amd.default_params(rho_scale=4.0, max_iters=400)
-nodes, _ = omc_amd.pkg.bnb.expand_frontier(eng, int(sys.argv[1]) if len(sys.argv) > 1 else 4, c["cut_type"], params=P); nodes = nodes[:64]
+nodes, _ = omc_amd.pkg.bnb.expand_frontier(eng, int(sys.argv[1]) if len(sys.argv) > 1 else 4, c["cut_type"], params=P); nodes = nodes[:int(sys.argv[2]) if len(sys.argv) > 2 else 64]
 out = eng.matrix_completion_SDP_relaxation(nodes, c["cut_type"], params=P, want_Y=False, want_X=False)
 st = np.zeros(32); _lib.check(eng._lib.omc_debug_stamps(eng._h, _lib.ptr(st)))
 its = out[0]["iters"]
