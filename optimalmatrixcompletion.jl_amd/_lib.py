@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libomc_hip.so")
+# OMC_AMD_LIB points the loader at another build of the same library (the instrumented `make stamps` build, an A/B variant)
+LIB_PATH = os.environ.get("OMC_AMD_LIB") or os.path.join(_HERE, "lib", "libomc_hip.so")
 
 EXPORTS = [
     "omc_relax_params_default", "omc_last_error", "omc_version", "omc_device_count", "omc_instance_create",

@@ -1112,6 +1112,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   // seed the tracked subspace (k_cone_sub) with the SUBP dominant eigenvectors when few eigenvalues are positive
   if (w.sub_enable) {
     const bool seed = s_nkeep <= SUBP - SUBG && N >= 3 * SUBP;
+    if (w.sub_debug == 3 && tid == 0) atomicAdd(&w.stamps[(s_nkeep < 31) ? s_nkeep : 31], 1.0);      // diagnostics: positive eigenvalues seen by the full kernel
     if (seed) {
       if (tid == 0) {
         for (int j = 0; j < SUBP; ++j) {

@@ -12,4 +12,4 @@ t0 = time.perf_counter()
 out = eng.matrix_completion_SDP_relaxation(nodes, c["cut_type"], params=P, want_Y=False, want_X=False)
 el = time.perf_counter() - t0
 it = np.array([o["iters"] for o in out]); st = np.bincount([o["status_code"] for o in out], minlength=4)
-print("config 3: %d nodes in %.2fs = %.1f node-relaxations/s; status %s iters median %d; kernel ms %s; info %s" % (len(nodes), el, len(nodes) / el, st, np.median(it), {k: round(v["ms"]) for k, v in eng.kernel_stats().items()}, eng.solver_info()))
+print("config 3: %d nodes in %.2fs = %.1f node-relaxations/s; status %s iters median %d; kernel ms %s; info %s; sub %s" % (len(nodes), el, len(nodes) / el, st, np.median(it), {k: round(v["ms"]) for k, v in eng.kernel_stats().items()}, eng.solver_info(), eng.subspace_stats()))

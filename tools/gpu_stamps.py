@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import omc_amd
 from omc_amd_pkg import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "lib_stamps", "libomc_hip.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "lib_stamps", "libomc_hip.so")
 _lib._lib = None
 A, mask, gamma, c = omc_amd.pkg.data.config_instance(2, seed=0)
 eng = omc_amd.Engine(A, mask, gamma, c["k"])
