@@ -142,6 +142,7 @@ def main():
     n, m, k = cfg["n"], cfg["m"], cfg["k"]
     eng = omc_amd.Engine(A, mask, gamma, k, device=local)
     use_comm = world > 1 or bool(os.environ.get("OMC_BENCH_FORCE_COMM"))     # the env var exercises the exchange path with a world of one
+    lib_comm = False; comm_kind = None
     if use_comm:    # the library's own RCCL communicator (C ABI); torch.distributed only carries the 128-byte id to the ranks
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
@@ -149,7 +150,18 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1)
         box = [eng.comm_unique_id().tobytes() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        eng.comm_init(rank, world, np.frombuffer(box[0], dtype=np.uint8))
+        comm_kind = "omc_allreduce_bounds (library RCCL communicator)"
+        try:
+            eng.comm_init(rank, world, np.frombuffer(box[0], dtype=np.uint8))
+            ok = 1
+        except Exception as e:          # e.g. a second RCCL instance refused by the runtime: the bounds then travel over torch.distributed (RCCL too)
+            print(f"bench.py rank {rank}: omc_comm_init failed ({e}); falling back to torch.distributed all_reduce", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
+        lib_comm = bool(int(flag[0]))
+        if not lib_comm:
+            comm_kind = "torch.distributed all_reduce (RCCL); omc_comm_init failed"
     cache = args.frontier_file if world == 1 else None
     if cache and os.path.exists(cache):
         import pickle
@@ -185,10 +197,19 @@ def main():
         eng.solve()
         out = eng.fetch(want_Y=False, want_X=False)
         ub = min(o["objective"] for o in out); lb = min(o["dual_bound"] for o in out)
-        if use_comm:
+        if use_comm and lib_comm:
             ub, lb, _ = eng.allreduce_bounds(ub, lb)
+        elif use_comm:
+            t = torch.tensor([ub, lb], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ub, lb = float(t[0]), float(t[1])
         return (ub, lb), out
 
+    # every launch of the timed steps is bracketed by HIP events: hipGraph replay of the iteration body (the library's path for <= 16 live
+    # slots, whose kernels events cannot see) is switched off for them, so that the per-kernel averages below and rocprofv3's describe the
+    # same launches; the extras (latency_b1, branching) run with the library default
+    graph_env = os.environ.get("OMC_GRAPH_MAX")
+    os.environ["OMC_GRAPH_MAX"] = "0"
     for _ in range(args.warmup):
         step()
     kstats = {}; sub = {}
@@ -244,6 +265,10 @@ def main():
                                 "the kernels back to back (profiles/ has both)",
                     kernel_ms=per_kernel)
 
+    if graph_env is None:
+        os.environ.pop("OMC_GRAPH_MAX", None)
+    else:
+        os.environ["OMC_GRAPH_MAX"] = graph_env
     extras = {}
     if rank == 0 and world == 1 and args.extras:
         # ---- single-node-at-a-time (BASELINE config 2 wording): batch 1, the reference's serial order --------------------------------
@@ -296,6 +321,7 @@ def main():
                        "nodes_per_gpu": B, "slots": min(args.slots, B), "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
                        "status_counts": {"optimal": int(status[0]), "slow_progress": int(status[1]), "time_limit": int(status[2]), "infeasible": int(status[3])},
                        "certified_fraction": certified / B, "certified_nodes_per_s": value * certified / B,
+                       "bounds_exchange": (comm_kind if use_comm else None),
                        "jacobi_sweeps_last_step": info["jacobi_sweeps"], "instance_sha256": data.instance_sha256(A, mask)[:16]},
             "roofline": roofline, "cpu_baseline": extras.get("cpu_baseline"), "time_to_gap": extras.get("time_to_gap"),
             "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"),
