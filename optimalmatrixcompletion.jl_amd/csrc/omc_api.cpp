@@ -455,6 +455,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.sub_on = h->bsubI.as<int>(); w.cone_done = h->bsubI.as<int>() + sB; w.sub_stat = h->bsubI.as<int>() + 2 * sB; w.sub_wait = h->bsubI.as<int>() + 10 * sB; w.sub_nfail = h->bsubI.as<int>() + 11 * sB;
     w.sub_qmax = getenv("OMC_SUB_QMAX") ? atoi(getenv("OMC_SUB_QMAX")) : 24;
     w.sub_chunk = getenv("OMC_SUB_CHUNK") ? atoi(getenv("OMC_SUB_CHUNK")) : 3;
+    w.sub_lazy = getenv("OMC_SUB_LAZY") ? atoi(getenv("OMC_SUB_LAZY")) : 1;
     w.sub_tol = getenv("OMC_SUB_TOL") ? atof(getenv("OMC_SUB_TOL")) : 1e-10;
     w.sub_adapt = getenv("OMC_SUB_ADAPT") ? atof(getenv("OMC_SUB_ADAPT")) : 1e-3;
     w.sub_debug = getenv("OMC_SUB_DEBUG") ? atoi(getenv("OMC_SUB_DEBUG")) : 0;

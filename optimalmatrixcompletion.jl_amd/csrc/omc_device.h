@@ -74,7 +74,7 @@ struct OmcWS {
   int ws_ld;              // leading dimension of G in k_cone_ws (chosen on the host: 16 mod 32 when it fits)
   // tracked top-16 subspace of the cone input (k_cone_sub): once Y has settled, clip(M, 0, 1) = sum over the FEW positive eigenpairs
   // (config 2: 2 of 100), so only the dominant invariant subspace is followed from one ADMM iteration to the next
-  int sub_enable, sub_qmax, sub_chunk, sub_debug; double sub_tol, sub_adapt;
+  int sub_enable, sub_qmax, sub_chunk, sub_debug, sub_lazy; double sub_tol, sub_adapt;   // sub_lazy: orthonormalise once per chunk instead of after every power step
   double* Xs;             // B * np16 * 16: orthonormal Ritz basis (column-major, ld = np16, zero padded rows)
   double* sub_theta;      // B * 16: Ritz values of the last accepted call
   double* trM;            // B: trace of Mbuf (with fro2 it bounds the untracked part of the spectrum)

@@ -1169,8 +1169,8 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   extern __shared__ double smem[];
-  __shared__ int s_flag, s_nsel;
-  __shared__ double s_shift;
+  __shared__ int s_flag, s_nsel, s_cond;
+  __shared__ double s_shift, s_cs[SUBP];
   const int b = (MODE == 0) ? slot_of(w, blockIdx.x) : (int)blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   if (MODE == 2) {
     if (!w.fin[b] || !w.sub_on[b]) return;      // separation of a harvested slot, seeded by the block that followed Y - D1
@@ -1286,7 +1286,13 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       if (hi > 1e299) hi = mu;
       double lo = fmax(mu - sqrt(var * (nr - 1.0)), mu - 3.0 * sqrt(var));
       if (lo_t < 1e299) lo = fmin(lo, lo_t - 0.05 * (hi - lo_t));
-      if (lane == 0) s_shift = -0.5 * (lo + hi);
+      double tmax = (lane < SUBP) ? tj : -1e300;
+      for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o, WAVE));
+      // column j is (close to) the Ritz vector of theta_j and grows by theta_j + s per unorthogonalised step: dividing it out keeps the
+      // block near orthonormal between the orthonormalisations of a chunk
+      const double sh = -0.5 * (lo + hi);
+      if (lane < SUBP) s_cs[lane] = 1.0 / fmax(fabs(tj + sh), 1e-3 * fmax(fabs(tmax + sh), 1e-300));
+      if (lane == 0) s_shift = sh;
     }
     __syncthreads();
     const double shift = s_shift;
@@ -1295,63 +1301,82 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       mul_MX(shift);
       __syncthreads();
       SUBSTAMP(2);
-      gram(Za, Za);
-      SUBSTAMP(3);
-      if (wv == 0) {
-        // Cholesky of the Gram matrix in REGISTERS: lane i < 16 holds row i, pivots and multipliers travel by v_readlane (no LDS
-        // round trips, no barrier); then column j of L^-1 by forward substitution in lane j.  ~1.5 k instructions, one wave.
-        double c[SUBP];
-        const int i = (lane < SUBP) ? lane : SUBP - 1;
-#pragma unroll
-        for (int q = 0; q < SUBP; ++q) c[q] = Hs[i * 17 + q];
-        int bad = 0;
-#pragma unroll
-        for (int j = 0; j < SUBP; ++j) {
-          const double d = readlane_d(c[j], j);
-          if (!(d > 1e-280)) bad = 1;
-          const double inv = rsqrt(fmax(d, 1e-280));
-          const double lj = c[j] * inv;                 // L[i][j] for i >= j (lane j: sqrt(d))
-#pragma unroll
-          for (int q = j + 1; q < SUBP; ++q) c[q] = fma(-lj, readlane_d(lj, q), c[q]);
-          c[j] = lj;
-        }
-        if (lane < SUBP) {
-#pragma unroll
-          for (int q = 0; q < SUBP; ++q) Gj[lane * 17 + q] = (q <= lane) ? c[q] : 0.0;      // L (lower triangle) -> Gj
-        }
-        WAVE_SYNC();
-        // L^-1: lane j solves L z = e_j; the result goes to Hs as Linv[i][j]
-        double z[SUBP];
-#pragma unroll
-        for (int r = 0; r < SUBP; ++r) {
-          double v = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-          for (int q = 0; q < SUBP; ++q) if (q < r) v = fma(-Gj[r * 17 + q], z[q], v);
-          z[r] = v / Gj[r * 17 + r];
-        }
-        WAVE_SYNC();
-        if (lane < SUBP) {
-#pragma unroll
-          for (int r = 0; r < SUBP; ++r) Hs[r * 17 + lane] = (r >= lane) ? z[r] : 0.0;       // Linv[r][j = lane]
-        }
-        if (lane == 0) s_flag = bad;
+      if (MODE != 2 && w.sub_lazy && c + 1 < chunk) {
+        // inside a chunk the block is only rescaled: the span after `chunk` steps is the same, and the condition of the block grows by
+        // at most (largest / smallest shifted Ritz value)^chunk, which the orthonormalisation at the end of the chunk absorbs (it is
+        // repeated once when its pivots say the block had become ill-conditioned)
+        for (int e = tid; e < SUBP * NP; e += T) { const int j = e / NP, r = e - j * NP; Xa[(size_t)j * LD + r] = s_cs[j] * Za[(size_t)j * LD + r]; }
+        __syncthreads();
+        SUBSTAMP(5);
+        ++steps;
+        continue;
       }
-      __syncthreads();
-      SUBSTAMP(4);
-      if (s_flag) { fail = 3; break; }
-      {   // X = Y L^-T by MFMA: X[row][j] = sum_q Y[row][q] Linv[j][q]  (a row tile of X depends on the same rows of Y only)
-        for (int ti = wv; ti < nt; ti += 4) {
-          const int i0 = ti << 4;
-          double4v a1 = {0.0, 0.0, 0.0, 0.0};
+      for (int pass = 0; pass < 2; ++pass) {
+        gram(Za, Za);
+        SUBSTAMP(3);
+        if (wv == 0) {
+          // Cholesky of the Gram matrix in REGISTERS: lane i < 16 holds row i, pivots and multipliers travel by v_readlane (no LDS
+          // round trips, no barrier); then column j of L^-1 by forward substitution in lane j.  ~1.5 k instructions, one wave.
+          double c[SUBP];
+          const int i = (lane < SUBP) ? lane : SUBP - 1;
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], Hs[li * 17 + 4 * u + lk], a1, 0, 0, 0);
+          for (int q = 0; q < SUBP; ++q) c[q] = Hs[i * 17 + q];
+          int bad = 0;
+          double dmin = 1e300, dmax = 0.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Xa[(size_t)li * LD + i0 + lk + 4 * r] = a1[r];
+          for (int j = 0; j < SUBP; ++j) {
+            const double d = readlane_d(c[j], j);
+            if (!(d > 1e-280)) bad = 1;
+            dmin = fmin(dmin, d); dmax = fmax(dmax, d);
+            const double inv = rsqrt(fmax(d, 1e-280));
+            const double lj = c[j] * inv;                 // L[i][j] for i >= j (lane j: sqrt(d))
+#pragma unroll
+            for (int q = j + 1; q < SUBP; ++q) c[q] = fma(-lj, readlane_d(lj, q), c[q]);
+            c[j] = lj;
+          }
+          if (lane < SUBP) {
+#pragma unroll
+            for (int q = 0; q < SUBP; ++q) Gj[lane * 17 + q] = (q <= lane) ? c[q] : 0.0;      // L (lower triangle) -> Gj
+          }
+          WAVE_SYNC();
+          // L^-1: lane j solves L z = e_j; the result goes to Hs as Linv[i][j]
+          double z[SUBP];
+#pragma unroll
+          for (int r = 0; r < SUBP; ++r) {
+            double v = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < SUBP; ++q) if (q < r) v = fma(-Gj[r * 17 + q], z[q], v);
+            z[r] = v / Gj[r * 17 + r];
+          }
+          WAVE_SYNC();
+          if (lane < SUBP) {
+#pragma unroll
+            for (int r = 0; r < SUBP; ++r) Hs[r * 17 + lane] = (r >= lane) ? z[r] : 0.0;       // Linv[r][j = lane]
+          }
+          if (lane == 0) { s_flag = bad; s_cond = (pass == 0 && w.sub_lazy && dmin < 1e-6 * dmax) ? 1 : 0; }   // pivot ratio ~ cond(block)^2
         }
+        __syncthreads();
+        SUBSTAMP(4);
+        if (s_flag) { fail = 3; break; }
+        const bool again = s_cond != 0;
+        {   // X = Y L^-T by MFMA: X[row][j] = sum_q Y[row][q] Linv[j][q]  (a row tile of X depends on the same rows of Y only)
+          double* Xo = again ? Za : Xa;            // second pass: the result goes back into Za (a wave reads its tile completely before it writes)
+          for (int ti = wv; ti < nt; ti += 4) {
+            const int i0 = ti << 4;
+            double4v a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Za[(size_t)(4 * u + lk) * LD + i0 + li], Hs[li * 17 + 4 * u + lk], a1, 0, 0, 0);
+            WAVE_SYNC();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xo[(size_t)li * LD + i0 + lk + 4 * r] = a1[r];
+          }
+        }
+        __syncthreads();
+        SUBSTAMP(5);
+        if (!again) break;
       }
-      __syncthreads();
-      SUBSTAMP(5);
+      if (fail) break;
       ++steps;
     }
     if (fail) break;
