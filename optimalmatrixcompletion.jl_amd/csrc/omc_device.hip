@@ -1316,8 +1316,9 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
         SUBSTAMP(3);
         if (wv == 0) {
           // Cholesky of the Gram matrix in REGISTERS: lane i < 16 holds row i, pivots and multipliers travel by v_readlane (no LDS
-          // round trips, no barrier); then column j of L^-1 by forward substitution in lane j.  ~1.5 k instructions, one wave.
-          double c[SUBP];
+          // round trips, no barrier); then column j of L^-1 by forward substitution in lane j, the rows of L again by v_readlane (an
+          // LDS copy of L made the compiler hoist all 136 broadcast loads: 430 VGPRs, one workgroup per CU).  ~1.5 k instructions, one wave.
+          double c[SUBP], dinv[SUBP];
           const int i = (lane < SUBP) ? lane : SUBP - 1;
 #pragma unroll
           for (int q = 0; q < SUBP; ++q) c[q] = Hs[i * 17 + q];
@@ -1329,26 +1330,21 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
             if (!(d > 1e-280)) bad = 1;
             dmin = fmin(dmin, d); dmax = fmax(dmax, d);
             const double inv = rsqrt(fmax(d, 1e-280));
+            dinv[j] = inv;                                // 1 / L[j][j]
             const double lj = c[j] * inv;                 // L[i][j] for i >= j (lane j: sqrt(d))
 #pragma unroll
             for (int q = j + 1; q < SUBP; ++q) c[q] = fma(-lj, readlane_d(lj, q), c[q]);
             c[j] = lj;
           }
-          if (lane < SUBP) {
-#pragma unroll
-            for (int q = 0; q < SUBP; ++q) Gj[lane * 17 + q] = (q <= lane) ? c[q] : 0.0;      // L (lower triangle) -> Gj
-          }
-          WAVE_SYNC();
-          // L^-1: lane j solves L z = e_j; the result goes to Hs as Linv[i][j]
+          // L^-1: lane j solves L z = e_j; L[r][q] lives in lane r and arrives by v_readlane; the result goes to Hs as Linv[i][j]
           double z[SUBP];
 #pragma unroll
           for (int r = 0; r < SUBP; ++r) {
             double v = (r == i) ? 1.0 : 0.0;
 #pragma unroll
-            for (int q = 0; q < SUBP; ++q) if (q < r) v = fma(-Gj[r * 17 + q], z[q], v);
-            z[r] = v / Gj[r * 17 + r];
+            for (int q = 0; q < SUBP; ++q) if (q < r) v = fma(-readlane_d(c[q], r), z[q], v);
+            z[r] = v * dinv[r];
           }
-          WAVE_SYNC();
           if (lane < SUBP) {
 #pragma unroll
             for (int r = 0; r < SUBP; ++r) Hs[r * 17 + lane] = (r >= lane) ? z[r] : 0.0;       // Linv[r][j = lane]
