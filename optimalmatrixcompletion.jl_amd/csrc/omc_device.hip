@@ -1435,6 +1435,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
     if (MODE >= 1) {
       if (tid == 0) {      // only the largest Ritz values have to be accurate: MODE 1 the k most negative eigenvalues of Mchk, MODE 2 two
         int bad = 0; double used[8]; const int kk = (MODE == 2) ? 2 : ((w.k < 8) ? w.k : 8);
+        const int kreq = (MODE == 2 && w.breakpoints != 2) ? 1 : kk;      // smallest_1_eigvec uses the first pair only; the second eigenvalue is then informative
         double ssum = 0.0;
         for (int q = 0; q < kk; ++q) {
           int bi = -1; double bl = -1e300;
@@ -1444,7 +1445,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
             if (!u_ && th[t] > bl) { bl = th[t]; bi = t; }
           }
           used[q] = (double)bi;
-          if (!(evj[bi] <= tol_eff * fmax(nF, 1e-300))) bad = 1;
+          if (q < kreq && !(evj[bi] <= tol_eff * fmax(nF, 1e-300))) bad = 1;
           ssum += fmax(bl, 0.0);
           if (MODE == 2) sel[q] = bi;
         }
