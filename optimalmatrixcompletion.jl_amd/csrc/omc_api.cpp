@@ -1327,6 +1327,10 @@ int omc_debug_residuals(omc_instance* h, double* rp, double* rd) {
 
 int omc_debug_stamps(omc_instance* h, double* out32) {
   if (!h || !out32 || !h->ws.stamps) return fail(OMC_ERR_ARGUMENT, "no stamps");
+  if (getenv("OMC_SUB_DEBUG") && atoi(getenv("OMC_SUB_DEBUG")) == 3 && h->ws.B >= 8) {      // diagnostics: three histograms (tools/diagnostics/gpu_nkeep_hist.py passes 96 doubles)
+    HIPCHK(hipMemcpy(out32, h->ws.stamps, 96 * 8, hipMemcpyDeviceToHost));
+    return 0;
+  }
   HIPCHK(hipMemcpy(out32, h->ws.stamps, 32 * 8, hipMemcpyDeviceToHost));
   return 0;
 }

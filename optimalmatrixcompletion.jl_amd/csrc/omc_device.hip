@@ -1091,6 +1091,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
       if (lamv > 0.0) ++nkeep;
     }
     s_nkeep = nkeep;
+    if (w.sub_debug == 3) { const int mn = (ndef < nkeep) ? ndef : nkeep; atomicAdd(&w.stamps[32 + ((ndef < 31) ? ndef : 31)], 1.0); atomicAdd(&w.stamps[64 + ((mn < 31) ? mn : 31)], 1.0); }   // diagnostics
     int c = 0;
     if (ndef <= nkeep) {
       for (int t = 0; t < N; ++t) {

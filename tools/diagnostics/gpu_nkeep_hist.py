@@ -13,9 +13,11 @@ nodes, _ = omc_amd.pkg.bnb.expand_frontier(eng, depth, c["cut_type"], params=P)
 z = np.zeros(32); 
 P = omc_amd.default_params(rho_scale=4.0, slots=len(nodes))
 eng.stage(nodes, c["cut_type"], P)
-out0 = np.zeros(32); omc_amd.load().omc_debug_stamps(eng._h, out0.ctypes.data_as(C.c_void_p))
+out0 = np.zeros(96); omc_amd.load().omc_debug_stamps(eng._h, out0.ctypes.data_as(C.c_void_p))
 eng.solve()
-out = np.zeros(32); omc_amd.load().omc_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p))
+out = np.zeros(96); omc_amd.load().omc_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p))
 h = out - out0
-print("config", cfgi, "nodes", len(nodes), "full calls", int(h.sum()), "sub", eng.subspace_stats())
-print("nkeep histogram (31 = 31 or more):", {i: int(v) for i, v in enumerate(h) if v})
+print("config", cfgi, "nodes", len(nodes), "full calls", int(h[:32].sum()), "sub", eng.subspace_stats())
+print("positive eigenvalues (31 = 31 or more):", {i: int(v) for i, v in enumerate(h[:32]) if v})
+print("eigenvalues outside [0, 1] (the defect side):", {i: int(v) for i, v in enumerate(h[32:64]) if v})
+print("min of the two (what a two-sided block would have to hold):", {i: int(v) for i, v in enumerate(h[64:96]) if v})
