@@ -280,6 +280,26 @@ def test_dense_columns_and_deep_paths(have_gpu, omc, orc):
     eng.close()
 
 
+def test_more_than_sixteen_cut_rows(have_gpu, omc, orc):
+    """k_global forms the quadratic forms x' tY x of the cut rows 16 at a time on the matrix cores and stages 16 active cut vectors in LDS:
+    nodes with 18 and 21 cuts take the second pass and the beyond-16 path of the final update."""
+    n, m = 18, 22
+    A, mask = orc.make_instance(n, m, 1, seed=77, kind="readme")
+    inst = orc.Instance(A, mask, GAMMA, 1)
+    nodes = oracle_path(orc, inst, "linear", 21, 16.0, seed=5)
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    sel = [nodes[16], nodes[18], nodes[21]]
+    out = eng.matrix_completion_SDP_relaxation(sel, "linear", params=omc.default_params(rho_scale=16.0))
+    for g, c in zip(out, sel):
+        r = orc.sdp_relaxation(inst, c, "linear", params=orc.RelaxParams(rho_scale=16.0), want_certificate=False)
+        assert_finite(g)
+        assert g["status_code"] == r["termination_status"], (len(c), g["status_code"], r["termination_status"])
+        if g["status_code"] != 3:
+            assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
+            assert abs(g["iters"] - r["iters"]) <= 25, (len(c), g["iters"], r["iters"])
+    eng.close()
+
+
 def test_large_order_uses_l2_resident_path(have_gpu, omc, orc):
     """n = 150: G of the cone kernel (150 x 162 x 8 B) and the target of k_global do not fit the LDS budget -> L2-resident
     variants of the same kernels.  Oracle comparison on the root (the oracle needs ~1 min here)."""
