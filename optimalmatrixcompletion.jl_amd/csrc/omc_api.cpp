@@ -596,7 +596,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       w.cert_enable = (w.sub_enable && w.MbufC && getenv("OMC_CERT_SUB")) ? 1 : 0;
       w.sep_done = (w.sub_enable && !getenv("OMC_NO_SEP_SUB")) ? h->bsubIC.as<int>() + 2 * sB : nullptr;   // opt-in: measured no gain (the eigenvalues are not what the check spends its time on) and fewer rigorous samples of the bound
     }
-    h->glob_lds = ((size_t)n * m + (size_t)n * k + (size_t)rmax * k + 3 * Rmax + 8 + 16 * (size_t)n) * 8 + 16;   // n*m >= n*n: the region also stages Lambda; 16 = GL_XS staged cut vectors
+    h->glob_lds = ((size_t)n * (n + 1) / 2 + (size_t)n * k + (size_t)rmax * k + 3 * Rmax + 8 + 16 * (size_t)n) * 8 + 16;   // packed lower triangle of the target; 16 = GL_XS staged cut vectors
     h->glob_use_lds = (h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS) && !getenv("OMC_GLOBAL_NOLDS");   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
     if (!h->glob_use_lds) {
       w.glob_scratch_stride = h->glob_lds / 8 + 8;

@@ -1559,8 +1559,8 @@ __global__ void __launch_bounds__(256) k_sep_prepare(OmcWS w) {
 // ---------------------------------------------------------------------------------------------------------
 // C = L L' for a dense column-major n x m matrix L (zero off the support of the observed pattern) by v_mfma_f64_16x16x4_f64,
 // one 16 x 16 tile of the lower triangle per wave and pass, operands straight from L2.  store(i, j, v) receives every entry of
-// the tile with i >= j inside the matrix (the caller mirrors).  Used where the output-stationary LDS formulation of k_global does
-// not fit (n > 144): there the per-entry walk over the CSR lists cost 4.8 ms per node at n = 200.
+// the tile with i >= j inside the matrix.  k_global (every order) and k_check_build (n > 144) use it: the per-entry walk over the CSR
+// lists that it replaced did a fifth of the flops and cost 41 us of 108 per node at n = 100, 4.8 ms at n = 200.
 // ---------------------------------------------------------------------------------------------------------
 template <class StoreF>
 __device__ __forceinline__ void mfma_LLt(const double* L, int n, int m, StoreF store) {
@@ -1602,61 +1602,6 @@ __device__ __forceinline__ void mfma_LLt(const double* L, int n, int m, StoreF s
     for (int r = 0; r < 4; ++r) {
       const int i = (ti << 4) + lk + 4 * r, j = (tj << 4) + li;
       if (i < n && j < n && i >= j) store(i, j, acc[r]);
-    }
-  }
-}
-
-// The same product with L staged in LDS and the tiles kept in registers (wave w owns the lower-triangle tiles w, w + nw, ..: at most
-// MAXT of them), because the LDS region of L is overwritten by the target before the product is added to it (k_global).
-template <int MAXT>
-__device__ __forceinline__ void mfma_LLt_tiles(const double* L, int n, int m, double4v (&accT)[MAXT]) {
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6, li = lane & 15, lk = lane >> 4;
-  const int nt = (n + 15) >> 4, ntile = nt * (nt + 1) / 2;
-#pragma unroll
-  for (int u = 0; u < MAXT; ++u) {
-    const int tile = wv + u * nw;
-    double4v acc = {0.0, 0.0, 0.0, 0.0};
-    if (tile < ntile) {                               // wave-uniform
-      int ti = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-      while (ti * (ti + 1) / 2 > tile) --ti;
-      while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-      const int tj = tile - ti * (ti + 1) / 2;
-      const int ia = (ti << 4) + li, jb = (tj << 4) + li;
-      const bool va = ia < n, vb = jb < n;
-      const double* La = L + (va ? ia : 0);
-      const double* Lb = L + (vb ? jb : 0);
-      const int m4 = m & ~3;
-      int k0 = 0;
-      for (; k0 < m4; k0 += 4) {
-        const double a = La[(size_t)(k0 + lk) * n], bv = Lb[(size_t)(k0 + lk) * n];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va ? a : 0.0, vb ? bv : 0.0, acc, 0, 0, 0);
-      }
-      if (k0 < m) {
-        const int kk = k0 + lk; const bool vk = kk < m; const int kc = vk ? kk : 0;
-        const double a = La[(size_t)kc * n], bv = Lb[(size_t)kc * n];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((va && vk) ? a : 0.0, (vb && vk) ? bv : 0.0, acc, 0, 0, 0);
-      }
-    }
-    accT[u] = acc;
-  }
-}
-template <int MAXT, class StoreF>
-__device__ __forceinline__ void mfma_LLt_emit(int n, const double4v (&accT)[MAXT], StoreF store) {
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6, li = lane & 15, lk = lane >> 4;
-  const int nt = (n + 15) >> 4, ntile = nt * (nt + 1) / 2;
-#pragma unroll
-  for (int u = 0; u < MAXT; ++u) {
-    const int tile = wv + u * nw;
-    if (tile < ntile) {
-      int ti = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-      while (ti * (ti + 1) / 2 > tile) --ti;
-      while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-      const int tj = tile - ti * (ti + 1) / 2;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = (ti << 4) + lk + 4 * r, j = (tj << 4) + li;
-        if (i < n && j < n && i >= j) store(i, j, accT[u][r]);
-      }
     }
   }
 }
@@ -1879,8 +1824,11 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const int nb = w.node_of[b];
   const int n = w.n, k = w.k, m = w.m, rm = w.rmax;
   const int R = w.R[nb], r = w.rr[nb];
+  // The target is symmetric: only its lower triangle is kept, packed by rows (entry (i, j), i >= j, at i (i + 1) / 2 + j) -- 40 KB instead
+  // of 80 KB at n = 100, which is what lets two workgroups share a CU.
   auto tY = [&]() { if constexpr (USE_LDS) return (double*)smem; else return w.glob_scratch + (size_t)b * w.glob_scratch_stride; }();
-  double* tU = tY + (size_t)n * m;       // n*k   (tU, then the full-space U correction); the first region is n*m >= n*n doubles
+  auto TRIX = [](int i, int j) { return (i >= j) ? ((i * (i + 1)) >> 1) + j : ((j * (j + 1)) >> 1) + i; };
+  double* tU = tY + (size_t)n * (n + 1) / 2;       // n*k   (tU, then the full-space U correction)
   double* tV = tU + (size_t)n * k;       // rm*k
   double* cvec = tV + (size_t)rm * k;    // Rmax
   double* mu = cvec + w.Rmax;            // Rmax
@@ -1899,27 +1847,17 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   const double rho = w.rho_b[b], rho_f = rho * w.rho_f_ratio, rx = w.relax, g = w.gamma;
   STAMP_BEGIN();
   DIAG_T0();
-  // 1. gamma/2 * Lambda Lambda' on the matrix cores (deterministic: one wave owns a tile).  LDS path: the dense column-major copy of
-  //    Lambda (written by k_colprox, zero where a row is not observed) is staged in LDS -- in the region that holds the target
-  //    afterwards -- and every wave keeps its <= GL_MAXT lower-triangle tiles in registers.  (The walk over the CSR lists that this
-  //    replaces did a fifth of the flops and took 41 us of the 108 us of this kernel at n = m = 100.)
-  constexpr int GL_MAXT = 6;                             // tiles per wave: 45 lower-triangle tiles (n <= 144) over 8 waves
-  double4v accLL[GL_MAXT];
+  // 1. (the product gamma/2 * Lambda Lambda' is added to the target in step 2, by v_mfma_f64_16x16x4_f64 with the operands -- the dense
+  //    column-major copy of Lambda written by k_colprox, zero where a row is not observed -- straight from L2)
   const double* lamD = w.lamD + (size_t)b * m * n;
   const int nt16 = (n + 15) >> 4;
-  const bool ll_in_lds = USE_LDS && (nt16 * (nt16 + 1) / 2 <= GL_MAXT * (T >> 6));
-  if (ll_in_lds) {
-    double* LamS = tY;                                   // n*m doubles (region sized max(n*n, n*m) by the host)
-    for (int e = tid; e < n * m; e += T) LamS[e] = lamD[e];
-    __syncthreads();
-    mfma_LLt_tiles<GL_MAXT>(LamS, n, m, accLL);
-    __syncthreads();
-  }
   STAMP(8);
-  // 2. cone + multiplicity part of the target (+ the Lambda term)
+  // 2. cone + multiplicity part of the target (lower triangle), then the Lambda term, then the weights
   for (int e = tid; e < n * n; e += T) {
+    const int i = e % n, j = e / n;
+    if (i < j) continue;
     double y = Y[e];
-    tY[e] = rho_f * w.Ncnt[e] * y + rho * (rx * W1[e] + (1.0 - rx) * y + D1[e]) + rho * (y + (1.0 - rx) * D3[e] + rx * E3[e]);
+    tY[TRIX(i, j)] = rho_f * w.Ncnt[e] * y + rho * (rx * W1[e] + (1.0 - rx) * y + D1[e]) + rho * (y + (1.0 - rx) * D3[e] + rx * E3[e]);
   }
   for (int e = tid; e < r * k; e += T) {
     int a = e % r, j = e / r;
@@ -1927,22 +1865,12 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   }
   for (int e = tid; e < R; e += T) mu[e] = lam[e] / rho;
   __syncthreads();
-  if (ll_in_lds) {
-    mfma_LLt_emit<GL_MAXT>(n, accLL, [&](int i, int j, double v) {
-      const double t = 0.5 * g * v;
-      tY[(size_t)j * n + i] += t;
-      if (i != j) tY[(size_t)i * n + j] += t;
-    });
-  } else {
-    // large orders: Lambda Lambda' as a dense MFMA product of the zero-padded copy (deterministic: one wave owns a tile)
-    mfma_LLt(lamD, n, m, [&](int i, int j, double v) {
-      const double t = 0.5 * g * v;
-      tY[(size_t)j * n + i] += t;
-      if (i != j) tY[(size_t)i * n + j] += t;
-    });
-  }
+  mfma_LLt(lamD, n, m, [&](int i, int j, double v) { tY[TRIX(i, j)] += 0.5 * g * v; });      // one wave owns a tile: deterministic
   __syncthreads();
-  for (int e = tid; e < n * n; e += T) tY[e] /= (rho * w.wY1[e]);
+  for (int e = tid; e < n * n; e += T) {
+    const int i = e % n, j = e / n;
+    if (i >= j) tY[TRIX(i, j)] /= (rho * w.wY1[e]);
+  }
   for (int e = tid; e < n * k; e += T) {
     int i = e % n, j = e / n;
     double acc = 0.0;
@@ -1977,12 +1905,11 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
       const double* xc = xs + (size_t)(vc ? li : 0) * n;
       double qsum = 0.0;
       for (int ti = wv_; ti < nt16; ti += nw_) {
-        const int ia = (ti << 4) + li; const bool va = ia < n;
-        const double* Ta = tY + (va ? ia : 0);
+        const int ia = (ti << 4) + li; const bool va = ia < n; const int ic = va ? ia : 0;
         double4v acc = {0.0, 0.0, 0.0, 0.0};
         for (int k0 = 0; k0 < n; k0 += 4) {
           const int kk = k0 + lk; const bool vk = kk < n; const int kc = vk ? kk : 0;
-          const double a = Ta[(size_t)kc * n], bv = xc[kc];
+          const double a = tY[TRIX(ic, kc)], bv = xc[kc];
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64((va && vk) ? a : 0.0, (vc && vk) ? bv : 0.0, acc, 0, 0, 0);
         }
 #pragma unroll
@@ -2011,7 +1938,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
       const int kind = w.rkind[(size_t)nb * w.Rmax + rr];
       double acc = 0.0;
       if (kind == ROW_TRACE) {
-        for (int i = lane_; i < n; i += WAVE) acc += tY[(size_t)i * n + i];
+        for (int i = lane_; i < n; i += WAVE) acc += tY[TRIX(i, i)];
       } else if (kind == ROW_BOX) {
         if (lane_ == 0) acc = w.rcoef[((size_t)nb * w.Rmax + rr) * k] * tU[(size_t)w.rbj[(size_t)nb * w.Rmax + rr] * n + w.rbi[(size_t)nb * w.Rmax + rr]];
       } else {
@@ -2093,8 +2020,8 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     double corr = (i == j) ? s_trace_mu : 0.0;
     for (int a = 0; a < nstg; ++a) { const double* x = xs + (size_t)a * n; corr += s_mu[a] * (x[i] * x[j]); }             // (x_i x_j) first: exactly symmetric in (i, j)
     for (int a = nstg; a < nact; ++a) { const double* x = cutx + (size_t)s_act[a] * n; corr += s_mu[a] * (x[i] * x[j]); }
-    const size_t a1 = (size_t)j * n + i, a2 = (size_t)i * n + j;
-    const double t = 0.5 * (tY[a1] + tY[a2]);
+    const size_t a1 = (size_t)j * n + i;
+    const double t = tY[TRIX(i, j)];
     const double yn = t - corr / w.wY1[a1];
     const double yold = Y[a1];
     const double w1 = W1[a1], e3 = E3[a1], d3 = D3[a1];

@@ -301,20 +301,29 @@ def test_more_than_sixteen_cut_rows(have_gpu, omc, orc):
 
 
 def test_large_order_uses_l2_resident_path(have_gpu, omc, orc):
-    """n = 150: G of the cone kernel (150 x 162 x 8 B) and the target of k_global do not fit the LDS budget -> L2-resident
-    variants of the same kernels.  Oracle comparison on the root (the oracle needs ~1 min here)."""
+    """n = 150: G of the cone kernel (150 x 162 x 8 B) does not fit the LDS budget -> L2-resident variant of that kernel; the packed
+    lower triangle of k_global's target (91 KB) still does (its L2-resident variant runs at n = 200, test_order_200_l2_resident_variants_agree).
+    Oracle comparison on the root (the oracle needs ~1 min here)."""
     n, m, k = 150, 150, 1
     A, mask = orc.make_instance(n, m, k, seed=61, kind="lowrank", n_indices=int(0.15 * n * m))
     eng = omc.Engine(A, mask, GAMMA, k)
     P = omc.default_params(rho_scale=4.0, max_iters=400)
     g = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P)[0]
     info = eng.solver_info()
-    assert not info["cone_lds"] and not info["global_lds"]
+    assert not info["cone_lds"] and info["global_lds"]
     inst = orc.Instance(A, mask, GAMMA, k)
     r = orc.sdp_relaxation(inst, params=orc.RelaxParams(rho_scale=4.0, max_iters=400), want_certificate=False)
     assert g["iters"] == r["iters"] and g["status_code"] == r["termination_status"]
     assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
     assert g["dual_bound"] == pytest.approx(r["dual_bound"], rel=1e-5)
+    os.environ["OMC_GLOBAL_NOLDS"] = "1"            # the same solve with the target of k_global in its L2-resident scratch
+    try:
+        g2 = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P)[0]
+        assert not eng.solver_info()["global_lds"]
+    finally:
+        del os.environ["OMC_GLOBAL_NOLDS"]
+    assert g2["iters"] == g["iters"] and g2["status_code"] == g["status_code"]
+    assert g2["objective"] == pytest.approx(g["objective"], rel=1e-10) and g2["dual_bound"] == pytest.approx(g["dual_bound"], rel=1e-8)
     eng.close()
 
 
