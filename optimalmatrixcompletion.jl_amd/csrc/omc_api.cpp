@@ -680,14 +680,17 @@ int omc_relax_solve(omc_instance* h) {
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
   }
-  // compact list of the slots that hold a node: the per-iteration kernels launch over it (rebuilt after every refill)
+  // compact list of the slots that hold a running node: the per-iteration kernels launch over it (rebuilt when slots finish or are refilled)
+  std::vector<char> parked(S, 0);      // finished, waiting for the next harvest
+  int check_index = 0;
+  const int refill_every = std::max(1, getenv("OMC_REFILL_EVERY") ? atoi(getenv("OMC_REFILL_EVERY")) : 3);
   std::vector<int> alist(S);
   for (int b = 0; b < S; ++b) alist[b] = b;
   int nlist = S;
   const bool use_list = !(getenv("OMC_NO_SLOT_LIST"));
   auto push_list = [&]() -> int {
     nlist = 0;
-    for (int b = 0; b < S; ++b) if (node_of[b] >= 0) alist[nlist++] = b;
+    for (int b = 0; b < S; ++b) if (node_of[b] >= 0 && !parked[b]) alist[nlist++] = b;
     if (nlist) HIPCHK(hipMemcpyAsync(h->bslotlist.p, alist.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
@@ -813,9 +816,22 @@ int omc_relax_solve(omc_instance* h) {
       }
     }
     // harvest finished slots, hand them the next pending nodes
+    // Harvest and refill every `refill_every`-th check only (or when nothing is left running): a refilled slot spends its first dozen
+    // iterations in the full eigendecomposition, the straggler of every launch it is part of, and each harvest is 1 - 3 ms of few-workgroup
+    // kernels on the main stream -- batching them halves the launches that carry young slots.  A finished slot waits (done = 1, skipped
+    // by every kernel and left out of the slot list) for at most refill_every - 1 check intervals.
     std::vector<int> init(S, 0), fin(S, 0);
-    int nfin = 0;
-    for (int b = 0; b < S; ++b) if (node_of[b] >= 0 && done[b]) { fin[b] = 1; ++nfin; }
+    int nfin = 0, nlive = 0, nnew = 0;
+    for (int b = 0; b < S; ++b) {
+      if (node_of[b] < 0) continue;
+      if (done[b]) { ++nfin; if (!parked[b]) { parked[b] = 1; ++nnew; } } else ++nlive;
+    }
+    ++check_index;
+    // with pending nodes: every refill_every-th check, at once when the live slots no longer fill the chip; without: the finished slots can
+    // wait longer (nothing to hand them), until nothing runs any more
+    const bool harvest_now = nfin > 0 && (nlive == 0 || (next < Btot ? (check_index % refill_every == 0 || nlive < 256) : (check_index % (4 * refill_every) == 0)));
+    if (harvest_now) for (int b = 0; b < S; ++b) if (node_of[b] >= 0 && done[b]) { fin[b] = 1; parked[b] = 0; }
+    if (!harvest_now) nfin = 0;
     if (nfin) {
       int rc = push_flags(init, fin); if (rc) return rc;
       TIMED(OMC_KERNEL_HARVEST, nfin, {
@@ -836,8 +852,8 @@ int omc_relax_solve(omc_instance* h) {
       if (ninit) TIMED(OMC_KERNEL_SETUP, ninit, omc_launch_setup(&w, s));
     }
     nactive = 0; gact[0] = gact[1] = 0;
-    for (int b = 0; b < S; ++b) if (node_of[b] >= 0) { ++nactive; ++gact[(G == 2 && b >= gb0[1]) ? 1 : 0]; }
-    if (nfin) { int rc = push_list(); if (rc) return rc; }
+    for (int b = 0; b < S; ++b) if (node_of[b] >= 0) { ++nactive; if (!parked[b]) ++gact[(G == 2 && b >= gb0[1]) ? 1 : 0]; }
+    if (nfin || nnew) { int rc = push_list(); if (rc) return rc; }
     if (timed_out && next < Btot) {
       // nodes that never got a slot: report TIME_LIMIT without values
       std::vector<int> st(Btot - next, OMC_ST_TIME), itz(Btot - next, 0);
