@@ -447,12 +447,13 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   }
   w.Mbuf = h->bMbuf.as<double>(); w.Vrow = h->bVrow.as<double>();
   {   // tracked subspace of the cone block (k_cone_sub)
-    ENS(h->bXs, sB * w.np16 * 16 * 8); ENS(h->bsubS, sB * 17 * 8); ENS(h->bsubI, sB * 12 * sizeof(int));
+    ENS(h->bXs, sB * w.np16 * 16 * 8); ENS(h->bsubS, sB * (17 + 256) * 8); ENS(h->bsubI, sB * 13 * sizeof(int));
     HIPCHK(hipMemsetAsync(h->bXs.p, 0, sB * w.np16 * 16 * 8, h->stream));
-    HIPCHK(hipMemsetAsync(h->bsubS.p, 0, sB * 17 * 8, h->stream));
-    HIPCHK(hipMemsetAsync(h->bsubI.p, 0, sB * 12 * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->bsubS.p, 0, sB * (17 + 256) * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->bsubI.p, 0, sB * 13 * sizeof(int), h->stream));
     w.Xs = h->bXs.as<double>(); w.sub_theta = h->bsubS.as<double>(); w.trM = h->bsubS.as<double>() + sB * 16;
     w.sub_on = h->bsubI.as<int>(); w.cone_done = h->bsubI.as<int>() + sB; w.sub_stat = h->bsubI.as<int>() + 2 * sB; w.sub_wait = h->bsubI.as<int>() + 10 * sB; w.sub_nfail = h->bsubI.as<int>() + 11 * sB;
+    w.V3 = getenv("OMC_SMALL_COLD") ? nullptr : h->bsubS.as<double>() + sB * 17; w.v3valid = h->bsubI.as<int>() + 12 * sB;
     w.sub_qmax = getenv("OMC_SUB_QMAX") ? atoi(getenv("OMC_SUB_QMAX")) : 24;
     w.sub_chunk = getenv("OMC_SUB_CHUNK") ? atoi(getenv("OMC_SUB_CHUNK")) : 3;
     w.sub_lazy = getenv("OMC_SUB_LAZY") ? atoi(getenv("OMC_SUB_LAZY")) : 1;

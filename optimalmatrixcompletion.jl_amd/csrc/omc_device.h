@@ -78,6 +78,7 @@ struct OmcWS {
   double* Xs;             // B * np16 * 16: orthonormal Ritz basis (column-major, ld = np16, zero padded rows)
   double* sub_theta;      // B * 16: Ritz values of the last accepted call
   double* trM;            // B: trace of Mbuf (with fro2 it bounds the untracked part of the spectrum)
+  double* V3; int* v3valid;  // B * 256, B: eigenvectors of the last small-cone projection (order <= 16), warm start of the next one (NULL: cold every time)
   int *sub_wait, *sub_nfail; // B: iterations left before the subspace is tried again after a failure ; failures so far (back-off)
   int *sub_on, *cone_done;   // B: slot follows the subspace ; this iteration's W1 has been written by k_cone_sub
   // certificate estimator (k_cone_sub<1>): block of the most negative eigenvectors of Mchk, its Ritz values (of -Mchk), trace of MbufC

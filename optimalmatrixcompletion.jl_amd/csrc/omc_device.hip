@@ -83,7 +83,7 @@ __global__ void k_setup(OmcWS w) {
       w.Vrow[(size_t)b * NP * NP + e] = 0.0;
     }
     if (tid == 0) {
-      w.fro2[b] = d0 * d0 * n; w.trM[b] = d0 * n; w.sub_on[b] = 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
+      w.fro2[b] = d0 * d0 * n; w.trM[b] = d0 * n; w.sub_on[b] = 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.v3valid[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
     }
   }
   for (int e = tid; e < n * k; e += T) w.U[(size_t)b * n * k + e] = 0.0;
@@ -1700,7 +1700,36 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   STAMP(17);
   if (N3 == 0) return;
   auto entry = [&](int i, int j) { return M3[(size_t)j * ld3 + i]; };
-  const double sigma = eig_frontend(Gm, ev, N3, Np, ld, entry, red, &s_cnt, nullptr);
+  double sigma;
+  if (mode == SMALL_PROJ && Np <= 16 && w.V3) {
+    // order <= 16: one-sided Jacobi inside one wave on G = (M3 + sigma I) V_prev -- M3 moves little from one ADMM iteration to the next,
+    // so the columns start almost orthogonal (two sweeps instead of the six of a cold start); the normalised columns are the eigenvectors
+    // and are kept for the next iteration
+    double* Vp = w.V3 + (size_t)b * 256;
+    const bool warm = w.v3valid[b] != 0;
+    double fro = 0.0;
+    for (int e = tid; e < N3 * N3; e += T) { const int i = e % N3, j = e / N3; const double v = 0.5 * (entry(i, j) + entry(j, i)); fro += v * v; }
+    fro = sqrt(block_sum(fro, red));
+    sigma = 1.5 * fro + 1e-300;
+    for (int e = tid; e < Np * Np; e += T) {
+      const int i = e % Np, t = e / Np;
+      double v = 0.0;
+      if (i < N3 && t < N3) {
+        if (warm) { for (int j = 0; j < N3; ++j) v += (0.5 * (entry(i, j) + entry(j, i)) + ((i == j) ? sigma : 0.0)) * Vp[t * 16 + j]; }
+        else v = 0.5 * (entry(i, t) + entry(t, i)) + ((i == t) ? sigma : 0.0);
+      }
+      Gm[(size_t)t * ld + i] = v;
+    }
+    __syncthreads();
+    if (tid < WAVE) jacobi_sweeps_wave16(Gm, ev, N3, Np, ld, 1e-14, 30);
+    __syncthreads();
+    for (int t = tid; t < N3; t += T) { double a = 0.0; for (int i = 0; i < N3; ++i) { const double x = Gm[(size_t)t * ld + i]; a += x * x; } ev[t] = a; }
+    __syncthreads();
+    for (int e = tid; e < N3 * N3; e += T) { const int i = e % N3, t = e / N3; Vp[t * 16 + i] = Gm[(size_t)t * ld + i] * rsqrt(ev[t]); }
+    if (tid == 0) w.v3valid[b] = 1;
+  } else {
+    sigma = eig_frontend(Gm, ev, N3, Np, ld, entry, red, &s_cnt, nullptr);
+  }
   if (mode == SMALL_RECOVER) {
     // pinv weights: S^+ = sum_{lam > tol} (1/lam) v v' ;  v = g/nu  ->  weight 1/(lam nu^2)
     if (tid == 0) {
