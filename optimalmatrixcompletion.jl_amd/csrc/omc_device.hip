@@ -1643,35 +1643,35 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   // T1 = (Y - D3) Q   or  Y Q
   constexpr int T1_RS = 16;
   if (USE_LDS && r <= T1_RS && n <= T) {
-    // Q' staged in LDS, padded to 16 columns: the inner loop has no conditional loads (a guarded load keeps hipcc from
-    // overlapping the memory latencies).  One thread per (row i, slice of the j range): every Y / D3 entry is loaded once.
+    // Q' staged in LDS, padded to 16 columns (zero beyond column r)
     for (int e = tid; e < n * T1_RS; e += T) { const int j = e / T1_RS, a = e % T1_RS; Qs[e] = (a < r) ? Q[(size_t)a * n + j] : 0.0; }
     __syncthreads();
-    int H = T / n; if (H > 8) H = 8;
-    const int i = tid % n, hh = tid / n;
-    double acc[T1_RS];
+    {
+      // (Y - D3) Q on the matrix cores: wave w owns the 16-row tiles w, w + 4, ..; A = 16 x 4 blocks of Y - D3 straight from L2 (a column
+      // of the column-major matrix is contiguous over the 16 rows: 128-byte loads, every entry read once), B = the staged Q' from LDS
+      const int wv_ = tid >> 6, lane_ = tid & 63, li = lane_ & 15, lk = lane_ >> 4, nt = (n + 15) >> 4, nw_ = T >> 6;
+      const bool proj = (mode == SMALL_PROJ);
+      for (int ti = wv_; ti < nt; ti += nw_) {
+        const int ia = (ti << 4) + li; const bool va = ia < n; const int iac = va ? ia : 0;
+        double4v acc = {0.0, 0.0, 0.0, 0.0};
+        double ya[4], da[4];
 #pragma unroll
-    for (int a = 0; a < T1_RS; ++a) acc[a] = 0.0;
-    if (hh < H) {
-      const int j0 = (int)((long)n * hh / H), j1 = (int)((long)n * (hh + 1) / H);
-      if (mode == SMALL_PROJ) {
-        for (int j = j0; j < j1; ++j) {
-          const double yv = Y[(size_t)j * n + i] - D3[(size_t)j * n + i];
+        for (int u = 0; u < 4; ++u) { const int kk = 4 * u + lk, kc = (kk < n) ? kk : 0; ya[u] = Y[(size_t)kc * n + iac]; da[u] = proj ? D3[(size_t)kc * n + iac] : 0.0; }
+        for (int k0 = 0; k0 < n; k0 += 16) {
 #pragma unroll
-          for (int a = 0; a < T1_RS; ++a) acc[a] += yv * Qs[j * T1_RS + a];
+          for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + 4 * u + lk; const bool vk = kk < n;
+            const double av = ya[u] - da[u], bv = Qs[(vk ? kk : 0) * T1_RS + li];
+            const int kn = kk + 16, knc = (kn < n) ? kn : 0;          // prefetch of the next chunk (the value past the end is not used)
+            ya[u] = Y[(size_t)knc * n + iac]; da[u] = proj ? D3[(size_t)knc * n + iac] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((va && vk) ? av : 0.0, vk ? bv : 0.0, acc, 0, 0, 0);
+          }
         }
-      } else {
-        for (int j = j0; j < j1; ++j) {
-          const double yv = Y[(size_t)j * n + i];
 #pragma unroll
-          for (int a = 0; a < T1_RS; ++a) acc[a] += yv * Qs[j * T1_RS + a];
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int row = (ti << 4) + lk + 4 * r4;
+          if (row < n && li < r) T1[(size_t)li * n + row] = acc[r4];
         }
-      }
-    }
-    for (int h2 = 0; h2 < H; ++h2) {      // slices are added in a fixed order (deterministic sums)
-      if (hh == h2) {
-#pragma unroll
-        for (int a = 0; a < T1_RS; ++a) if (a < r) T1[(size_t)a * n + i] = (h2 == 0 ? 0.0 : T1[(size_t)a * n + i]) + acc[a];
       }
       __syncthreads();
     }
@@ -1809,12 +1809,26 @@ __global__ void __launch_bounds__(256) k_small(OmcWS w, int mode) {
   __syncthreads();
   double* E3 = w.E3 + (size_t)b * n * n;
   if (USE_LDS && r <= 16 && n <= T) {
-    // every entry on its own (coalesced stores, no transposed write): both operands come from LDS (T1 and the staged Q')
-    for (int e = tid; e < n * n; e += T) {
-      const int i = e % n, j = e / n;
-      double acc = 0.0;
-      for (int a = 0; a < r; ++a) acc += T1[(size_t)a * n + i] * Qs[j * 16 + a];
-      E3[e] = acc;
+    // rank-r product T1 Q' on the matrix cores: 16 x 16 tiles, K = 16 (the staged Q' is zero beyond column r), operands from LDS; the
+    // tile is written through its transposed position (E3 is symmetric), which makes the 16 lanes of a row store 128 contiguous bytes
+    const int wv_ = tid >> 6, lane_ = tid & 63, li = lane_ & 15, lk = lane_ >> 4, nt = (n + 15) >> 4, nw_ = T >> 6;
+    for (int tile = wv_; tile < nt * nt; tile += nw_) {
+      const int ti = tile / nt, tj = tile - ti * nt;
+      const int ia = (ti << 4) + li, jb = (tj << 4) + li;
+      const bool va = ia < n, vb = jb < n;
+      const int iac = va ? ia : 0, jbc = vb ? jb : 0;
+      double4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k0 = 0; k0 < 16; k0 += 4) {
+        const int a = k0 + lk; const bool vk = a < r;
+        const double av = T1[(size_t)(vk ? a : 0) * n + iac], bv = Qs[jbc * 16 + a];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((va && vk) ? av : 0.0, vb ? bv : 0.0, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = (ti << 4) + lk + 4 * r4, col = (tj << 4) + li;
+        if (row < n && col < n) E3[(size_t)row * n + col] = acc[r4];
+      }
     }
   } else {
     for (int e = tid; e < n * n; e += T) {
