@@ -152,6 +152,33 @@ int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int*
                     double* U, double* X, double* Theta, double* lambda_min, double* breakpoint_x,
                     double* solve_time);
 
+/* ---- relaxation with add_Shor_valid_inequalities = true (rank k = 1): OMC.jl:1431-1453 (keyword), 1503-1525 (W, V1, V2, V3),
+ * 1755-1779 (rotated cones, Theta_jj = sum_i W_ij, one order-5 PSD block per minor), 1838-1846 (objective), called at OMC.jl:747-754 with
+ * node.Shor_info = BBNodeShorInfo(constraints_indexes, SOC_constraints_indexes) (OMC.jl:37-40).
+ *   n_shor[b]   number of minors of node b; shor_idx: their (i1, i2, j1, j2) tuples, 1-based Int64, 4 per minor, all nodes concatenated
+ *               (node.Shor_info.constraints_indexes as Julia stores a Vector{NTuple{4,Int}});
+ *   n_soc[b]    number of SOC coordinates of node b; soc_idx: (i, j) 1-based Int64 pairs concatenated (SOC_constraints_indexes);
+ *               n_soc[b] = -1 (then the node contributes nothing to soc_idx) means "every coordinate that occurs in none of the node's
+ *               minors" -- what the reference's driver always passes (OMC.jl:656-673, 2508-2517) -- without shipping n*m pairs per node.
+ * Nodes with identical lists share one index structure on the device (the static mode hands every node the same list).
+ * Everything else as omc_relax_stage; then omc_relax_solve / omc_relax_submit / _wait and omc_relax_fetch as usual (X and Theta are
+ * the explicit variables of the Shor program), plus omc_relax_fetch_shor for W (OMC.jl:1908; V1, V2, V3 are not returned: the driver
+ * never reads them).  Status, objective (recomputed as OMC.jl:1960-1967 does) and the certified dual bound as in the base mode.
+ * rank k > 1 (Xt, Wt, H: OMC.jl:1526-1551, 1780-1827) returns OMC_ERR_UNSUPPORTED. */
+int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
+                         const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
+                         const double* U_upper, const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc,
+                         const int64_t* soc_idx);
+int omc_relax_fetch_shor(omc_instance* h, double* W /* n*m per node, may be NULL */);
+int omc_relax_batch_shor(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
+                         const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
+                         const double* U_upper, const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc,
+                         const int64_t* soc_idx, double* objective, double* dual_bound, int* status, int* iters, double* Y,
+                         double* U, double* X, double* Theta, double* W, double* lambda_min, double* breakpoint_x,
+                         double* solve_time);
+/* penalties of the Shor-mode splitting, in the scaled variables (defaults 0.05, 20, 2; params->rho_scale multiplies rho) */
+int omc_set_shor_penalties(omc_instance* h, double rho, double r4, double r5);
+
 /* ---- alternating_minimization (OMC.jl:1979-2279), disjunctive mode, B problems at once, rank k <= 4 --------
  * U_initial n*k per problem; cuts as above (only the per-cut bounds on v = U'x are imposed, OMC.jl:2047-2093);
  * k > 1 adds the pair cones ||U_j1 +- U_j2|| <= sqrt 2 of OMC.jl:2029-2045.
@@ -224,7 +251,10 @@ int omc_comm_destroy(omc_instance* h);
 #define OMC_KERNEL_CHECK_COL 8     /* certificate: exact f(Y) (one factorization per column, k_colprox mode 1) */
 #define OMC_KERNEL_CHECK_BUILD 9   /* certificate: Lagrangian matrix and constants (k_check_build) */
 #define OMC_KERNEL_HARVEST 10      /* finished slots: feasible U, separation eigenvector (OMC.jl:2466-2477), copy to the per-node outputs */
-#define OMC_KERNEL_NCLASS 11      /* OMC_KERNEL_CHECK = eigenvalues of the Lagrangian matrix + decisions */
+#define OMC_KERNEL_SHOR_BIGCONE 11 /* Shor mode: PSD projection of the order-(n+m) matrix [Y X; X' Theta] */
+#define OMC_KERNEL_SHOR_MINORS 12  /* Shor mode: order-5 blocks (projection in registers, duals) and the shared V1, V2, V3 */
+#define OMC_KERNEL_SHOR_COLS 13    /* Shor mode: per-column step (paraboloid, X, W, Theta, duals of the big cone) */
+#define OMC_KERNEL_NCLASS 14      /* OMC_KERNEL_CHECK = eigenvalues of the Lagrangian matrix + decisions */
 /* info[8]: solve seconds, total Jacobi sweeps of k_cone, rho, r_max, LDS flags (cone, global, small), R_max */
 int omc_last_solver_info(omc_instance* h, double* info);
 /* out[8] of the last omc_relax_solve: calls of k_cone_sub, its power steps, calls that fell back to the full eigendecomposition,

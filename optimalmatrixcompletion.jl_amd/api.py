@@ -2,7 +2,9 @@
 backed by the HIP library.  Reference = /root/reference/src/OptimalMatrixCompletion.jl (OMC.jl).
 
     Engine(A, indices, gamma, k)                  uploads (A, indices, gamma) once       (OMC.jl:470-471)
-    .matrix_completion_SDP_relaxation(nodes, ...) OMC.jl:1431-1943, a batch of nodes
+    .matrix_completion_SDP_relaxation(nodes, ...) OMC.jl:1431-1943, a batch of nodes; with `shor_info` = one (constraints_indexes,
+                                                  SOC_constraints_indexes) pair per node (BBNodeShorInfo, OMC.jl:37-40) the Shor-mode program
+                                                  (add_Shor_valid_inequalities = true, rank 1)
     .matrix_completion_master_feasible(Y, U)      OMC.jl:1261-1277
     .breakpoint_vectors(Y, U, breakpoints)        OMC.jl:2466-2477
     .evaluate_objective(X)                        OMC.jl:2330-2359
@@ -23,7 +25,8 @@ CUT_TYPES = {"linear": 0, "linear2": 1, "linear3": 2}
 DIR_CODES = {"left": 0, "middle": 1, "right": 2, "inner_left": 3, "inner_right": 4}
 BREAKPOINTS = {"smallest_1_eigvec": 1, "smallest_2_eigvec": 2}
 STATUS_NAMES = {0: "OPTIMAL", 1: "SLOW_PROGRESS", 2: "TIME_LIMIT", 3: "INFEASIBLE"}
-KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small", "accel", "cone_sub", "check_col", "check_build", "harvest"]
+KERNEL_CLASSES = ["colprox", "cone", "global", "check", "setup", "small", "accel", "cone_sub", "check_col", "check_build", "harvest",
+                  "shor_bigcone", "shor_minors", "shor_cols"]
 
 
 def default_params(**kw) -> RelaxParams:
@@ -104,6 +107,47 @@ class Engine:
                                              _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(lo), _lib.ptr(hi)))
         self._B = B
 
+    def stage_shor(self, nodes, shor_info, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None, penalties=None):
+        """Stage a batch with add_Shor_valid_inequalities = true (OMC.jl:747-754 with node.Shor_info).  shor_info[b] =
+        (constraints_indexes, SOC_constraints_indexes): 1-based (i1, i2, j1, j2) tuples and 1-based (i, j) pairs as the reference
+        holds them (OMC.jl:37-40); SOC_constraints_indexes = None means "every coordinate outside the minors" (what the reference's
+        driver always builds, OMC.jl:656-673, 2508-2517)."""
+        n, k = self.n, self.k
+        if len(shor_info) != len(nodes):
+            raise ValueError("one Shor_info per node")
+        if penalties is not None:
+            _lib.check(self._lib.omc_set_shor_penalties(self._h, float(penalties[0]), float(penalties[1]), float(penalties[2])))
+        L, cx, cU, cd = _pack_cuts(nodes, n, k, disjunctive_cuts_type)
+        p = params or default_params()
+        B = len(nodes)
+        lo = hi = None
+        if U_lower is not None:
+            lo = np.ascontiguousarray(np.stack([np.asfortranarray(u).ravel(order="F") for u in U_lower]))
+        if U_upper is not None:
+            hi = np.ascontiguousarray(np.stack([np.asfortranarray(u).ravel(order="F") for u in U_upper]))
+        nsh = np.zeros(B, np.int64); nso = np.zeros(B, np.int64); sh_parts = []; so_parts = []
+        for b, (minors, soc) in enumerate(shor_info):
+            mq = np.asarray(minors, np.int64).reshape(-1, 4)
+            nsh[b] = len(mq); sh_parts.append(mq)
+            if soc is None:
+                nso[b] = -1
+            else:
+                sq = np.asarray(soc, np.int64).reshape(-1, 2)
+                nso[b] = len(sq); so_parts.append(sq)
+        shi = np.ascontiguousarray(np.concatenate(sh_parts)) if sh_parts and sum(len(a) for a in sh_parts) else np.zeros((1, 4), np.int64)
+        soi = np.ascontiguousarray(np.concatenate(so_parts)) if so_parts and sum(len(a) for a in so_parts) else np.zeros((1, 2), np.int64)
+        self._keep = (L, cx, cU, cd, lo, hi, p, nsh, nso, shi, soi)
+        _lib.check(self._lib.omc_relax_stage_shor(self._h, B, C.byref(p), CUT_TYPES[disjunctive_cuts_type], _lib.ptr(L), _lib.ptr(cx),
+                                                  _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(lo), _lib.ptr(hi), _lib.ptr(nsh), _lib.ptr(shi),
+                                                  _lib.ptr(nso), _lib.ptr(soi)))
+        self._B = B
+
+    def fetch_shor(self):
+        """W of the last Shor-mode batch (results["W"], OMC.jl:1908), one (n, m) matrix per node."""
+        W = np.zeros((self._B, self.n * self.m))
+        _lib.check(self._lib.omc_relax_fetch_shor(self._h, _lib.ptr(W)))
+        return [W[b].reshape((self.n, self.m), order="F") for b in range(self._B)]
+
     def solve(self):
         _lib.check(self._lib.omc_relax_solve(self._h))
 
@@ -143,8 +187,20 @@ class Engine:
         return out
 
     def matrix_completion_SDP_relaxation(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None,
-                                         want_Y=True, want_X=True, want_Theta=False, rho_scales=None):
-        """Batch form of OMC.jl:1431-1943 (use_disjunctive_cuts = true, no Shor).  `nodes` = list of cut lists."""
+                                         want_Y=True, want_X=True, want_Theta=False, rho_scales=None, add_Shor_valid_inequalities=False,
+                                         shor_info=None, shor_penalties=None):
+        """Batch form of OMC.jl:1431-1943 (use_disjunctive_cuts = true).  `nodes` = list of cut lists; with
+        add_Shor_valid_inequalities = True, `shor_info` = one (constraints_indexes, SOC_constraints_indexes) pair per node and
+        every result also carries "W" (OMC.jl:1907-1908)."""
+        if add_Shor_valid_inequalities:
+            if shor_info is None:
+                raise ValueError("add_Shor_valid_inequalities = true needs node.Shor_info (OMC.jl:1508)")
+            self.stage_shor(nodes, shor_info, disjunctive_cuts_type, params, U_lower, U_upper, shor_penalties)
+            self.solve()
+            out = self.fetch(want_Y, want_X, want_Theta)
+            for r, Wb in zip(out, self.fetch_shor()):
+                r["W"] = Wb
+            return out
         self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper, rho_scales)
         self.solve()
         return self.fetch(want_Y, want_X, want_Theta)

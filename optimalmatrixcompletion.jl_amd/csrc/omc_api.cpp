@@ -24,6 +24,8 @@
 #include "omc_device.h"
 #include "omc_altmin.h"
 #include "omc_shor.h"
+#include "omc_shor_relax.h"
+#include <unordered_map>
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types only: the library is loaded with dlopen on first use, so that libomc_hip.so has no hard dependency on it
 
@@ -89,6 +91,12 @@ struct omc_instance {
   DevBuf sbits, scb, scx, scz, soff, stot, sout, shi, slo, sexist, shist, sohi, solo, scnt;
   bool shor_ready = false; int shor_W = 0; long long shor_pairs = 0;
   double shor_last_ms = 0; long long shor_last_candidates = 0;
+  // Shor-mode relaxation (omc_relax_stage_shor): index structures of the distinct lists, explicit X / W / Theta state, view of the workspace
+  // through which the base eigen-kernels project the order-(n+m) cone
+  bool shor_req = false, shor_on = false; double shor_rho = 0.05, shor_r4 = 20.0, shor_r5 = 2.0;
+  ShWS sh{}; OmcWS wbig{}; int big_lpp = 0, big_use_lds = 0, big_cone_lds_ok = 0; size_t big_lds = 0, big_cone_lds = 0;
+  DevBuf sgInts, sgBytes, sgGroups, sgNodeGroup, sAh, sX, sW, sTh, sV1, sV2, sV3, sD0, sP0, sMbufB, sVrowB, sTq, sPq, sNq, sD5x, sD5t, snu5, sP5x,
+      scolpart, sminpart, sminpart2, sfroB, svvB, se1, se2, soX, soW, soTh, sbigscr;
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
   size_t nnz_rows() const { return row_idx.size(); }
@@ -210,7 +218,10 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes, &h->blamDX, &h->bXsC, &h->bsubSC, &h->bsubIC,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
                    &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
-                   &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt};
+                   &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt,
+                   &h->sgInts, &h->sgBytes, &h->sgGroups, &h->sgNodeGroup, &h->sAh, &h->sX, &h->sW, &h->sTh, &h->sV1, &h->sV2, &h->sV3, &h->sD0, &h->sP0, &h->sMbufB, &h->sVrowB,
+                   &h->sTq, &h->sPq, &h->sNq, &h->sD5x, &h->sD5t, &h->snu5, &h->sP5x, &h->scolpart, &h->sminpart, &h->sminpart2, &h->sfroB, &h->svvB, &h->se1, &h->se2,
+                   &h->soX, &h->soW, &h->soTh, &h->sbigscr};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -271,7 +282,15 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type: must be linear, linear2 or linear3 (OMC.jl:1456-1462)");
   HIPCHK(hipSetDevice(h->device));
   h->staged = false;
+  const bool shor = h->shor_req;      // set by omc_relax_stage_shor for this call only
+  h->shor_req = false; h->shor_on = false;
   if (params) h->params = *params; else omc_relax_params_default(&h->params);
+  if (shor) {      // the bound of a Shor node lags its primal value for the first ~1000 iterations: no early stop, a longer stall window, one bump
+    h->params.early_stop_factor = 0.0;
+    h->params.stall_checks = std::max(h->params.stall_checks, 40);
+    h->params.bump_max = std::min(h->params.bump_max, 1);
+    h->params.first_wins = 0; h->params.accel = 0;
+  }
   const omc_relax_params& P = h->params;
   if (P.breakpoints != OMC_SMALLEST_1_EIGVEC && P.breakpoints != OMC_SMALLEST_2_EIGVEC)
     return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts breakpoints (OMC.jl:2440-2446)");
@@ -390,7 +409,9 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     const double sh = 1.0 + h->gamma * (double)k / (double)n;
     w.rho = P.rho_scale * 0.5 * h->gamma * h->sumA2 / ((double)m * sh * sh);
   }
+  if (shor) w.rho = h->shor_rho * P.rho_scale;      // penalty of the cone blocks in the scaled variables of the Shor splitting
   if (!(w.rho > 0.0)) w.rho = 1.0;
+  w.clip_hi = 1.0; w.inv_s2 = 1.0; w.shor = 0;
   w.rho_f_ratio = P.rho_f_ratio;
   w.bump_max = P.bump_max; w.bump_ratio = P.bump_ratio; w.bump_factor = P.bump_factor; w.bump_after = P.bump_after;
   w.bump_gap = P.bump_window * std::max(1, P.check_every);
@@ -417,7 +438,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.slot_list = nullptr;      // set on the per-iteration copies only (omc_relax_solve)
   }
   std::vector<double> wY((size_t)n * n);
-  for (size_t e = 0; e < (size_t)n * n; ++e) wY[e] = P.rho_f_ratio * h->Ncnt[e] + 2.0;
+  for (size_t e = 0; e < (size_t)n * n; ++e) wY[e] = shor ? 3.0 : P.rho_f_ratio * h->Ncnt[e] + 2.0;      // Shor mode: big cone, clip, small cone
   int rc_ = 0;
   if ((rc_ = upload(h->dwY, wY.data(), sizeof(double) * n * n, h->stream))) return rc_;
   w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
@@ -440,7 +461,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   HIPCHK(hipMemsetAsync(h->blamD.p, 0, sB * m * n * 8, h->stream));
   w.lamD = h->blamD.as<double>();
   w.lamDX = nullptr;
-  if (n > 144 || getenv("OMC_DENSE_CHECK")) {      // large orders: the certificate matrix takes Lambda Lambda' from one MFMA product
+  if (n > 144 || getenv("OMC_DENSE_CHECK") || shor) {      // large orders: the certificate matrix takes Lambda Lambda' from one MFMA product
     ENS(h->blamDX, sB * m * n * 8);
     HIPCHK(hipMemsetAsync(h->blamDX.p, 0, sB * m * n * 8, h->stream));
     w.lamDX = h->blamDX.as<double>();
@@ -662,6 +683,9 @@ int omc_relax_solve(omc_instance* h) {
     std::vector<int> init(S, 1), fin(S, 0);
     int rc = push_flags(init, fin); if (rc) return rc;
   }
+  const bool shor = h->shor_on;
+  const ShWS& sw = h->sh;
+  if (shor) omc_shor_launch_setup(&sw, s);       // before the base setup, which clears the init flags
   TIMED(OMC_KERNEL_SETUP, S, omc_launch_setup(&w, s));
   int it = 0;
   const int check = std::max(1, P.check_every);
@@ -719,6 +743,26 @@ int omc_relax_solve(omc_instance* h) {
     // the cone workgroups are few (two per CU, long serial phases) and the column waves many: the cone kernel goes first so that its
     // workgroups are resident when the column kernel floods the wave slots (OMC_COLPROX_FIRST=1 restores the other order)
     static const bool colprox_first = getenv("OMC_COLPROX_FIRST") != nullptr;
+    if (shor) {
+      // Shor mode: clip on the main stream, the order-(n+m) cone on the second, small cone + order-5 blocks on the third; then the
+      // global step: rows / Y (base kernel), columns (X, W, Theta, duals of the big cone), duals of the order-5 blocks, per-slot sums
+      OmcWS wb = h->wbig; wb.b0 = wg.b0; wb.nB = wg.nB; wb.slot_list = wg.slot_list;
+      if (w.sub_enable) MAYBE_TIMED(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
+      if (h->big_lpp) MAYBE_TIMED(sb, OMC_KERNEL_SHOR_BIGCONE, gact[g], omc_launch_cone_ws(&wb, h->big_lpp, h->big_use_lds, h->big_lds, sb));
+      else MAYBE_TIMED(sb, OMC_KERNEL_SHOR_BIGCONE, gact[g], omc_launch_cone(&wb, CONE_BIG, h->big_cone_lds_ok, h->big_cone_lds, sb));
+      if (h->ws_lpp) MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
+      else MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone(&wg, CONE_CLIP01, h->cone_use_lds, h->cone_lds, sm));
+      MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
+      MAYBE_TIMED(sc, OMC_KERNEL_SHOR_MINORS, gact[g], { omc_shor_launch_minor_pre(&sw, sc); omc_shor_launch_vkeys(&sw, sc); });
+      if (multi) {
+        HIPCHK(hipEventRecord(h->gev[g][1], sb)); HIPCHK(hipEventRecord(h->gev[g][2], sc));
+        HIPCHK(hipStreamWaitEvent(sm, h->gev[g][1], 0)); HIPCHK(hipStreamWaitEvent(sm, h->gev[g][2], 0));
+      }
+      MAYBE_TIMED(sm, OMC_KERNEL_GLOBAL, gact[g], omc_launch_global(&wg, h->glob_use_lds, h->glob_lds, sm));
+      MAYBE_TIMED(sm, OMC_KERNEL_SHOR_COLS, gact[g], omc_shor_launch_cols(&sw, sm));
+      MAYBE_TIMED(sm, OMC_KERNEL_SHOR_MINORS, gact[g], { omc_shor_launch_minor_post(&sw, sm); omc_shor_launch_reduce(&sw, sm); });
+      return 0;
+    }
     if (colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
     if (w.sub_enable) MAYBE_TIMED(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
     if (!colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
@@ -774,8 +818,8 @@ int omc_relax_solve(omc_instance* h) {
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     timed_out = el > P.time_limit;
     TIMED(OMC_KERNEL_CHECK_COL, nactive, {
-      omc_launch_check_zero(&w, s);
-      omc_launch_colprox(&w, 1, s);
+      if (shor) omc_shor_launch_check(&sw, s);      // primal value, constants and the dense multiplier of the Shor program
+      else { omc_launch_check_zero(&w, s); omc_launch_colprox(&w, 1, s); }
     });
     TIMED(OMC_KERNEL_CHECK_BUILD, nactive, omc_launch_check_build(&w, s));
     TIMED(OMC_KERNEL_CHECK, nactive, {
@@ -789,7 +833,7 @@ int omc_relax_solve(omc_instance* h) {
         else omc_launch_cone(&w, CONE_EVALS, h->cone_use_lds, h->cone_lds, s);
         omc_launch_check_final(&w, timed_out ? OMC_ST_TIME : 0, 2, s);      // per-slot iteration cap is applied on the device
       }
-      if (w.bump_max > 0) omc_launch_rho_rescale(&w, s);
+      if (w.bump_max > 0) { if (shor) omc_shor_launch_rescale(&sw, s); omc_launch_rho_rescale(&w, s); }
       if (w.accel) omc_launch_aa(&w, s);      // after the certificate (computed on an image of the map), skips finished slots
     });
     HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * S, hipMemcpyDeviceToHost, s));
@@ -840,6 +884,7 @@ int omc_relax_solve(omc_instance* h) {
         if (w.sep_done) omc_launch_sep_sub(&w, s);                                // separation vector from the tracked block where there is one
         omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, s);           // separation vector (OMC.jl:2466-2477)
         omc_launch_harvest(&w, s);
+        if (shor) omc_shor_launch_harvest(&sw, s);
       });
       harvested += nfin; h->nodes_done.store(harvested);
       int ninit = 0;
@@ -850,7 +895,7 @@ int omc_relax_solve(omc_instance* h) {
         else node_of[b] = -1;
       }
       rc = push_flags(init, fin); if (rc) return rc;
-      if (ninit) TIMED(OMC_KERNEL_SETUP, ninit, omc_launch_setup(&w, s));
+      if (ninit) { if (shor) omc_shor_launch_setup(&sw, s); TIMED(OMC_KERNEL_SETUP, ninit, omc_launch_setup(&w, s)); }
     }
     nactive = 0; gact[0] = gact[1] = 0;
     for (int b = 0; b < S; ++b) if (node_of[b] >= 0) { ++nactive; if (!parked[b]) ++gact[(G == 2 && b >= gb0[1]) ? 1 : 0]; }
@@ -934,7 +979,10 @@ int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int*
   if (U) HIPCHK(hipMemcpyAsync(U, w.oU, 8 * B * n * k, hipMemcpyDeviceToHost, s));
   if (lambda_min) HIPCHK(hipMemcpyAsync(lambda_min, w.olmin, 8 * 2 * B, hipMemcpyDeviceToHost, s));
   if (breakpoint_x) HIPCHK(hipMemcpyAsync(breakpoint_x, w.obx, 8 * B * n, hipMemcpyDeviceToHost, s));
-  if (X || Theta) {
+  if (h->shor_on) {
+    if (X) HIPCHK(hipMemcpyAsync(X, h->sh.oX, 8 * B * n * m, hipMemcpyDeviceToHost, s));
+    if (Theta) HIPCHK(hipMemcpyAsync(Theta, h->sh.oTh, 8 * B * m * m, hipMemcpyDeviceToHost, s));
+  } else if (X || Theta) {
     int r_ = h->bXout.ensure(8 * B * n * m); if (r_) return r_;
     omc_launch_make_X(&w, h->bXout.as<double>(), s);
     if (X) HIPCHK(hipMemcpyAsync(X, h->bXout.p, 8 * B * n * m, hipMemcpyDeviceToHost, s));
@@ -959,6 +1007,277 @@ int omc_relax_batch(omc_instance* h, int B, const omc_relax_params* params, int 
   rc = omc_relax_solve(h);
   if (rc) return rc;
   return omc_relax_fetch(h, objective, dual_bound, status, iters, Y, U, X, Theta, lambda_min, breakpoint_x, solve_time);
+}
+
+
+// ---- Shor mode (rank 1): matrix_completion_SDP_relaxation with add_Shor_valid_inequalities = true ---------------------------------------
+// OMC.jl:1503-1525, 1755-1779, 1838-1846; node.Shor_info lists OMC.jl:37-40.  Formulation: oracle/omc_oracle_shor.py, DESIGN.md 3.7.
+int omc_set_shor_penalties(omc_instance* h, double rho, double r4, double r5) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (!(rho > 0.0) || !(r4 > 0.0) || !(r5 > 0.0)) return fail(OMC_ERR_ARGUMENT, "penalties must be positive");
+  h->shor_rho = rho; h->shor_r4 = r4; h->shor_r5 = r5;
+  return 0;
+}
+
+namespace {
+struct ShorGroupHost {
+  int nq = 0, nv1 = 0, nv2 = 0;
+  std::vector<int> mi, kid, cptr, cent, v1ptr, v1ent, v2ptr, v2ent, slackrow;
+  std::vector<uint8_t> eclass, ctype;
+  size_t off_int = 0, off_byte = 0;       // offsets into the concatenated device buffers
+};
+// keys sorted, ids assigned in sorted order (as numpy.unique does in the oracle); members in increasing (minor, position) order
+static void build_keys(const std::vector<uint64_t>& keyA, const std::vector<uint64_t>& keyB, int nq, int& nkeys, int* kidA, int* kidB,
+                       std::vector<int>& ptr, std::vector<int>& ent) {
+  std::vector<std::pair<uint64_t, int>> all((size_t)2 * nq);
+  for (int q = 0; q < nq; ++q) { all[(size_t)2 * q] = {keyA[q], 2 * q}; all[(size_t)2 * q + 1] = {keyB[q], 2 * q + 1}; }
+  std::sort(all.begin(), all.end());
+  ptr.clear(); ent.resize((size_t)2 * nq);
+  nkeys = 0;
+  for (size_t e = 0; e < all.size(); ++e) {
+    if (e == 0 || all[e].first != all[e - 1].first) { ptr.push_back((int)e); ++nkeys; }
+    ent[e] = all[e].second;
+    const int q = all[e].second >> 1;
+    if (all[e].second & 1) kidB[q] = nkeys - 1; else kidA[q] = nkeys - 1;
+  }
+  ptr.push_back((int)all.size());
+}
+}  // namespace
+
+int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L, const double* cut_x,
+                         const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower, const double* U_upper,
+                         const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc, const int64_t* soc_idx) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (B <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
+  if (h->k != 1) return fail(OMC_ERR_UNSUPPORTED, "Shor mode is built for rank k = 1 (OMC.jl:1513-1525); the k > 1 form (Xt, Wt, H: OMC.jl:1526-1551, 1780-1827) is not");
+  if (!n_shor || !n_soc) return fail(OMC_ERR_ARGUMENT, "n_shor / n_soc is NULL");
+  const int n = h->n, m = h->m;
+  if ((long long)n * m >= (1ll << 30)) return fail(OMC_ERR_UNSUPPORTED, "Shor mode: n * m too large for the 32-bit index structures");
+  // ---- group the nodes by identical lists ------------------------------------------------------------------------------------------
+  std::vector<size_t> so(B + 1, 0), co(B + 1, 0);
+  for (int b = 0; b < B; ++b) {
+    if (n_shor[b] < 0 || n_soc[b] < -1) return fail(OMC_ERR_ARGUMENT, "negative list length");
+    if (n_shor[b] >= (1ll << 28)) return fail(OMC_ERR_UNSUPPORTED, "Shor mode: more than 2^28 minors in one node");
+    so[b + 1] = so[b] + (size_t)n_shor[b]; co[b + 1] = co[b] + (size_t)(n_soc[b] > 0 ? n_soc[b] : 0);
+  }
+  if (so[B] > 0 && !shor_idx) return fail(OMC_ERR_ARGUMENT, "shor_idx is NULL but n_shor > 0");
+  if (co[B] > 0 && !soc_idx) return fail(OMC_ERR_ARGUMENT, "soc_idx is NULL but n_soc > 0");
+  auto fnv = [](const void* p, size_t bytes, uint64_t hsh) { const uint8_t* c = (const uint8_t*)p; for (size_t e = 0; e < bytes; ++e) { hsh ^= c[e]; hsh *= 1099511628211ull; } return hsh; };
+  std::unordered_map<uint64_t, std::vector<int>> byhash;      // hash -> group ids
+  std::vector<int> rep;                                        // representative node of each group
+  std::vector<int> node_group(B);
+  for (int b = 0; b < B; ++b) {
+    uint64_t hv = 1469598103934665603ull;
+    hv = fnv(&n_shor[b], 8, hv); hv = fnv(&n_soc[b], 8, hv);
+    hv = fnv(shor_idx + 4 * so[b], 32 * (size_t)n_shor[b], hv);
+    if (n_soc[b] > 0) hv = fnv(soc_idx + 2 * co[b], 16 * (size_t)n_soc[b], hv);
+    int gid = -1;
+    for (int g : byhash[hv]) {
+      const int r = rep[g];
+      if (n_shor[r] == n_shor[b] && n_soc[r] == n_soc[b] && memcmp(shor_idx + 4 * so[r], shor_idx + 4 * so[b], 32 * (size_t)n_shor[b]) == 0 &&
+          (n_soc[b] <= 0 || memcmp(soc_idx + 2 * co[r], soc_idx + 2 * co[b], 16 * (size_t)n_soc[b]) == 0)) { gid = g; break; }
+    }
+    if (gid < 0) { gid = (int)rep.size(); rep.push_back(b); byhash[hv].push_back(gid); }
+    node_group[b] = gid;
+  }
+  const int NG = (int)rep.size();
+  std::vector<ShorGroupHost> gh(NG);
+  int nqmax = 0, nv1max = 0, nv2max = 0;
+  size_t tot_int = 0, tot_byte = 0;
+  for (int g = 0; g < NG; ++g) {
+    ShorGroupHost& G = gh[g];
+    const int b = rep[g];
+    const int nq = (int)n_shor[b];
+    G.nq = nq;
+    G.mi.resize((size_t)4 * nq); G.kid.resize((size_t)4 * nq);
+    std::vector<uint64_t> enc(nq), k1a(nq), k1b(nq), k2a(nq), k2b(nq);
+    std::vector<int> cnt((size_t)n * m + 1, 0);
+    for (int q = 0; q < nq; ++q) {
+      const int64_t* t = shor_idx + 4 * (so[b] + q);
+      const int64_t i1 = t[0] - 1, i2 = t[1] - 1, j1 = t[2] - 1, j2 = t[3] - 1;
+      if (!(0 <= i1 && i1 < i2 && i2 < n && 0 <= j1 && j1 < j2 && j2 < m))
+        return fail(OMC_ERR_ARGUMENT, "Shor minors must satisfy 1 <= i1 < i2 <= n, 1 <= j1 < j2 <= m (OMC.jl:2556-2603)");
+      G.mi[q] = (int)i1; G.mi[(size_t)nq + q] = (int)i2; G.mi[(size_t)2 * nq + q] = (int)j1; G.mi[(size_t)3 * nq + q] = (int)j2;
+      enc[q] = (((uint64_t)i1 * n + (uint64_t)i2) * m + (uint64_t)j1) * m + (uint64_t)j2;
+      k1a[q] = ((uint64_t)i1 * m + j1) * m + j2; k1b[q] = ((uint64_t)i2 * m + j1) * m + j2;      // V1[i,(j1,j2)]
+      k2a[q] = ((uint64_t)i1 * n + i2) * m + j1; k2b[q] = ((uint64_t)i1 * n + i2) * m + j2;      // V2[(i1,i2),j]
+      ++cnt[(size_t)j1 * n + i1]; ++cnt[(size_t)j2 * n + i1]; ++cnt[(size_t)j1 * n + i2]; ++cnt[(size_t)j2 * n + i2];
+    }
+    { std::vector<uint64_t> se = enc; std::sort(se.begin(), se.end()); if (std::adjacent_find(se.begin(), se.end()) != se.end()) return fail(OMC_ERR_ARGUMENT, "duplicate Shor minor in a node's list"); }
+    build_keys(k1a, k1b, nq, G.nv1, G.kid.data(), G.kid.data() + nq, G.v1ptr, G.v1ent);
+    build_keys(k2a, k2b, nq, G.nv2, G.kid.data() + (size_t)2 * nq, G.kid.data() + (size_t)3 * nq, G.v2ptr, G.v2ent);
+    // coordinate CSR: members in increasing (minor, position) order
+    G.cptr.assign((size_t)n * m + 1, 0);
+    for (size_t e = 0; e < (size_t)n * m; ++e) G.cptr[e + 1] = G.cptr[e] + cnt[e];
+    G.cent.resize((size_t)4 * nq);
+    { std::vector<int> fill(G.cptr.begin(), G.cptr.end() - 1);
+      for (int q = 0; q < nq; ++q) {
+        const int i1 = G.mi[q], i2 = G.mi[(size_t)nq + q], j1 = G.mi[(size_t)2 * nq + q], j2 = G.mi[(size_t)3 * nq + q];
+        const size_t ce[4] = {(size_t)j1 * n + i1, (size_t)j2 * n + i1, (size_t)j1 * n + i2, (size_t)j2 * n + i2};
+        for (int p = 0; p < 4; ++p) G.cent[fill[ce[p]]++] = 4 * q + p;
+      } }
+    // entry classes, column types, slack rows
+    G.eclass.assign((size_t)n * m, 0);
+    if (n_soc[b] < 0) { for (size_t e = 0; e < (size_t)n * m; ++e) G.eclass[e] = 1; }
+    else for (int64_t c = 0; c < n_soc[b]; ++c) {
+      const int64_t i = soc_idx[2 * (co[b] + c)] - 1, j = soc_idx[2 * (co[b] + c) + 1] - 1;
+      if (!(0 <= i && i < n && 0 <= j && j < m)) return fail(OMC_ERR_ARGUMENT, "SOC coordinate out of range");
+      G.eclass[(size_t)j * n + i] = 1;
+    }
+    for (size_t e = 0; e < (size_t)n * m; ++e) if (cnt[e] > 0) G.eclass[e] = 2;      // W >= X^2 is implied by the order-5 block there
+    G.ctype.assign(m, 2); G.slackrow.assign(m, -1);
+    for (int j = 0; j < m; ++j) {
+      int first_nonC = -1, first_unobs = -1;
+      for (int i = 0; i < n; ++i) {
+        if (G.eclass[(size_t)j * n + i] == 2) continue;
+        if (first_nonC < 0) first_nonC = i;
+        if (first_unobs < 0 && !h->mask[(size_t)j * n + i]) first_unobs = i;
+      }
+      if (first_unobs >= 0) { G.ctype[j] = 0; G.slackrow[j] = first_unobs; }
+      else if (first_nonC >= 0) { G.ctype[j] = 1; G.slackrow[j] = first_nonC; }
+    }
+    nqmax = std::max(nqmax, nq); nv1max = std::max(nv1max, G.nv1); nv2max = std::max(nv2max, G.nv2);
+    G.off_int = tot_int;
+    tot_int += G.mi.size() + G.kid.size() + G.cptr.size() + G.cent.size() + G.v1ptr.size() + G.v1ent.size() + G.v2ptr.size() + G.v2ent.size() + G.slackrow.size();
+    G.off_byte = tot_byte;
+    tot_byte += G.eclass.size() + G.ctype.size();
+    tot_byte = (tot_byte + 15) & ~(size_t)15;
+  }
+  // ---- base staging (rows, small cone, clip, certificate machinery) with the Shor flag ----------------------------------------------
+  h->shor_req = true;
+  int rc = omc_relax_stage(h, B, params, cut_type, L, cut_x, cut_Uhat, cut_dir, U_lower, U_upper);
+  h->shor_req = false;
+  if (rc) return rc;
+  h->staged = false;
+  OmcWS& w = h->ws;
+  const int S = w.B, N = n + m;
+  hipStream_t s = h->stream;
+  // ---- upload the index structures ------------------------------------------------------------------------------------------------
+  {
+    std::vector<int> hi(tot_int ? tot_int : 1); std::vector<uint8_t> hb(tot_byte ? tot_byte : 16, 0);
+    if ((rc = h->sgInts.ensure(hi.size() * sizeof(int)))) return rc;
+    if ((rc = h->sgBytes.ensure(hb.size()))) return rc;
+    std::vector<ShorGroupDev> gd(NG);
+    for (int g = 0; g < NG; ++g) {
+      ShorGroupHost& G = gh[g];
+      size_t o = G.off_int;
+      const int* base = h->sgInts.as<int>();
+      auto put = [&](const std::vector<int>& v) { const int* dp = base + o; if (!v.empty()) memcpy(&hi[o], v.data(), v.size() * sizeof(int)); o += v.size(); return dp; };
+      gd[g].nq = G.nq; gd[g].nv1 = G.nv1; gd[g].nv2 = G.nv2; gd[g].pad = 0;
+      gd[g].mi = put(G.mi); gd[g].kid = put(G.kid); gd[g].cptr = put(G.cptr); gd[g].cent = put(G.cent);
+      gd[g].v1ptr = put(G.v1ptr); gd[g].v1ent = put(G.v1ent); gd[g].v2ptr = put(G.v2ptr); gd[g].v2ent = put(G.v2ent); gd[g].slackrow = put(G.slackrow);
+      memcpy(&hb[G.off_byte], G.eclass.data(), G.eclass.size());
+      memcpy(&hb[G.off_byte + G.eclass.size()], G.ctype.data(), G.ctype.size());
+      gd[g].eclass = h->sgBytes.as<uint8_t>() + G.off_byte; gd[g].ctype = gd[g].eclass + G.eclass.size();
+    }
+    HIPCHK(hipMemcpyAsync(h->sgInts.p, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->sgBytes.p, hb.data(), hb.size(), hipMemcpyHostToDevice, s));
+    if ((rc = upload(h->sgGroups, gd.data(), sizeof(ShorGroupDev) * NG, s))) return rc;
+    if ((rc = upload(h->sgNodeGroup, node_group.data(), sizeof(int) * B, s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));          // the host vectors die with this block
+  }
+  // ---- scaling: the program is homogeneous of degree 2 in A (oracle: shor_scale) -------------------------------------------------------
+  const double sc = sqrt(((double)h->nnz / ((double)n * m)) * (double)std::min(n, m) / std::max(h->sumA2, 1e-300));
+  {
+    std::vector<double> Ah((size_t)n * m);
+    for (size_t e = 0; e < Ah.size(); ++e) Ah[e] = h->A[e] * sc;
+    if ((rc = upload(h->sAh, Ah.data(), 8 * Ah.size(), s))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  // ---- state ---------------------------------------------------------------------------------------------------------------------------
+  ShWS& sh = h->sh;
+  memset(&sh, 0, sizeof(sh));
+  const size_t sB = (size_t)S, sN = (size_t)B, nm = (size_t)n * m;
+  const int NPb = (N + 15) & ~15;
+  const int nmb = std::max(1, (nqmax + 255) / 256);
+  const size_t nq1 = (size_t)std::max(nqmax, 1), nv11 = (size_t)std::max(nv1max, 1), nv21 = (size_t)std::max(nv2max, 1);
+  ENS(h->sX, sB * nm * 8); ENS(h->sW, sB * nm * 8); ENS(h->sTh, sB * m * m * 8);
+  ENS(h->sV1, sB * nv11 * 8); ENS(h->sV2, sB * nv21 * 8); ENS(h->sV3, sB * nq1 * 8);
+  ENS(h->sD0, sB * N * N * 8); ENS(h->sP0, sB * N * N * 8); ENS(h->sMbufB, sB * NPb * NPb * 8); ENS(h->sVrowB, sB * NPb * NPb * 8);
+  ENS(h->sTq, sB * 15 * nq1 * 8); ENS(h->sPq, sB * 15 * nq1 * 8); ENS(h->sNq, sB * 15 * nq1 * 8);
+  ENS(h->sD5x, sB * nm * 8); ENS(h->sD5t, sB * m * 8); ENS(h->snu5, sB * m * 8); ENS(h->sP5x, sB * nm * 8);
+  ENS(h->scolpart, sB * m * 4 * 8); ENS(h->sminpart, sB * nmb * 8); ENS(h->sminpart2, sB * nmb * 8);
+  ENS(h->sfroB, sB * 8); ENS(h->svvB, sB * sizeof(int)); ENS(h->se1, sB * nv11 * 8); ENS(h->se2, sB * nv21 * 8);
+  ENS(h->soX, sN * nm * 8); ENS(h->soW, sN * nm * 8); ENS(h->soTh, sN * m * m * 8);
+  HIPCHK(hipMemsetAsync(h->sMbufB.p, 0, sB * NPb * NPb * 8, s));
+  HIPCHK(hipMemsetAsync(h->sVrowB.p, 0, sB * NPb * NPb * 8, s));
+  HIPCHK(hipMemsetAsync(h->sminpart.p, 0, sB * nmb * 8, s));
+  HIPCHK(hipMemsetAsync(h->sminpart2.p, 0, sB * nmb * 8, s));
+  HIPCHK(hipMemsetAsync(h->soX.p, 0, sN * nm * 8, s)); HIPCHK(hipMemsetAsync(h->soW.p, 0, sN * nm * 8, s)); HIPCHK(hipMemsetAsync(h->soTh.p, 0, sN * m * m * 8, s));
+  sh.n = n; sh.m = m; sh.N = N; sh.NPb = NPb; sh.S = S; sh.Btot = B; sh.nqmax = nqmax; sh.nv1max = nv1max; sh.nv2max = nv2max; sh.nmb = nmb;
+  sh.rx = w.relax; sh.r4 = h->shor_r4; sh.r5 = h->shor_r5; sh.gamma = h->gamma; sh.sc = sc;
+  sh.groups = h->sgGroups.as<ShorGroupDev>(); sh.node_group = h->sgNodeGroup.as<int>();
+  sh.node_of = w.node_of; sh.done = w.done; sh.init = w.init; sh.fin = w.fin; sh.rho_b = w.rho_b; sh.bfac = w.bfac;
+  sh.Ah = h->sAh.as<double>(); sh.mask = h->dmask.as<uint8_t>();
+  sh.X = h->sX.as<double>(); sh.W = h->sW.as<double>(); sh.Th = h->sTh.as<double>();
+  sh.V1 = h->sV1.as<double>(); sh.V2 = h->sV2.as<double>(); sh.V3 = h->sV3.as<double>();
+  sh.D0 = h->sD0.as<double>(); sh.P0 = h->sP0.as<double>(); sh.MbufB = h->sMbufB.as<double>(); sh.VrowB = h->sVrowB.as<double>();
+  sh.Tq = h->sTq.as<double>(); sh.Pq = h->sPq.as<double>(); sh.Nq = h->sNq.as<double>();
+  sh.D5x = h->sD5x.as<double>(); sh.D5t = h->sD5t.as<double>(); sh.nu5 = h->snu5.as<double>(); sh.P5x = h->sP5x.as<double>();
+  sh.colpart = h->scolpart.as<double>(); sh.minpart = h->sminpart.as<double>(); sh.minpart2 = h->sminpart2.as<double>();
+  sh.fro2B = h->sfroB.as<double>(); sh.vvalidB = h->svvB.as<int>();
+  sh.Y = w.Y; sh.Yp = w.Yp; sh.rp = w.rp; sh.rd = w.rd;
+  sh.e1 = h->se1.as<double>(); sh.e2 = h->se2.as<double>();
+  sh.objcol = w.objcol; sh.c0col = w.c0col; sh.lamDX = w.lamDX;
+  sh.oX = h->soX.as<double>(); sh.oW = h->soW.as<double>(); sh.oTh = h->soTh.as<double>();
+  // ---- base workspace in Shor mode, and the view through which its eigen-kernels project the order-(n+m) cone -------------------------
+  w.shor = 1; w.shN = N; w.shP0 = sh.P0; w.shD0 = sh.D0; w.inv_s2 = 1.0 / (sc * sc);
+  OmcWS& wb = h->wbig;
+  wb = w;
+  wb.n = N; wb.np16 = NPb; wb.Mbuf = sh.MbufB; wb.Vrow = sh.VrowB; wb.vvalid = sh.vvalidB; wb.fro2 = sh.fro2B; wb.W1 = sh.P0;
+  wb.sub_enable = 0; wb.cert_enable = 0; wb.ws_mode = 0; wb.clip_hi = 1e300; wb.sub_debug = 0;
+  {
+    const int Np2 = (N + 1) & ~1;
+    int lpp = 16; while (lpp > 4 && lpp * (Np2 / 2) > 512) lpp >>= 1;
+    int rpl = (((N + lpp - 1) / lpp) + 1) & ~1, Nrp = rpl * lpp;
+    int ldw = Nrp + ((16 - (Nrp & 31)) & 31);
+    if (((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64 > OMC_MAX_DYN_LDS) ldw = Nrp + 2;
+    h->big_lds = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
+    h->big_use_lds = h->big_lds <= OMC_MAX_DYN_LDS;
+    wb.ws_ld = ldw;
+    size_t need = 0;
+    if (!h->big_use_lds) {
+      lpp = 16; rpl = (((N + 15) / 16) + 1) & ~1; Nrp = rpl * 16; ldw = Nrp + 2; wb.ws_ld = ldw;
+      need = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
+    }
+    h->big_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
+    // generic cold kernel (orders beyond the warm-started one): Np x (Np | 1) matrix + 2 Np doubles + Np ints
+    const int ldc = Np2 | 1;
+    h->big_cone_lds = ((size_t)Np2 * ldc + 2 * Np2) * 8 + (size_t)Np2 * 4 + 16;
+    h->big_cone_lds_ok = h->big_cone_lds <= OMC_MAX_DYN_LDS;
+    if (!h->big_lpp && !h->big_cone_lds_ok) need = std::max(need, h->big_cone_lds);
+    if (need) {
+      wb.cone_scratch_stride = need / 8 + 8;
+      ENS(h->sbigscr, sB * wb.cone_scratch_stride * 8);
+      wb.cone_scratch = h->sbigscr.as<double>();
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  h->shor_on = true;
+  h->staged = true;
+  return 0;
+}
+
+int omc_relax_fetch_shor(omc_instance* h, double* W) {
+  if (!h || !h->staged || !h->shor_on) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch_shor: no Shor-mode batch staged");
+  HIPCHK(hipSetDevice(h->device));
+  if (W) HIPCHK(hipMemcpyAsync(W, h->sh.oW, 8 * (size_t)h->sh.Btot * h->n * h->m, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int omc_relax_batch_shor(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L, const double* cut_x,
+                         const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower, const double* U_upper,
+                         const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc, const int64_t* soc_idx, double* objective,
+                         double* dual_bound, int* status, int* iters, double* Y, double* U, double* X, double* Theta, double* W,
+                         double* lambda_min, double* breakpoint_x, double* solve_time) {
+  int rc = omc_relax_stage_shor(h, B, params, cut_type, L, cut_x, cut_Uhat, cut_dir, U_lower, U_upper, n_shor, shor_idx, n_soc, soc_idx);
+  if (rc) return rc;
+  rc = omc_relax_solve(h);
+  if (rc) return rc;
+  rc = omc_relax_fetch(h, objective, dual_bound, status, iters, Y, U, X, Theta, lambda_min, breakpoint_x, solve_time);
+  if (rc) return rc;
+  return omc_relax_fetch_shor(h, W);
 }
 
 int omc_evaluate_objective(omc_instance* h, int B, const double* X, double* objective) {
@@ -1026,6 +1345,9 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
                      double time_limit, double* U, double* V, int* converged, int* n_iters, double* objectives,
                      double* solve_time) {
   if (!h || !U_initial || !U || !V) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (B <= 0 || max_iters <= 0) return fail(OMC_ERR_ARGUMENT, "B and max_iters must be positive");
+  if (cut_type != OMC_CUT_LINEAR && cut_type != OMC_CUT_LINEAR2 && cut_type != OMC_CUT_LINEAR3)
+    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type (OMC.jl:1456-1462)");
   if (!(time_limit > 0.0)) {      // OMC.jl:2186-2189: the loop condition fails at once -- nothing is solved (a launch runs <= max_iters iterations in milliseconds, so this is the only case in which the limit can bind)
     const size_t nk = (size_t)h->n * h->k, mk = (size_t)h->m * h->k;
     for (int b = 0; b < B; ++b) { if (converged) converged[b] = 0; if (n_iters) n_iters[b] = 0; if (solve_time) solve_time[b] = 0.0; }

@@ -13,6 +13,7 @@
 #define CONE_EVALS 2
 #define CONE_SEP 3
 #define CONE_TOPK 4
+#define CONE_BIG 5     // Shor mode: PSD projection of the order-(n+m) matrix in Mbuf (view with n = n + m), output in W1
 #define SMALL_PROJ 0
 #define SMALL_RECOVER 1
 
@@ -84,6 +85,12 @@ struct OmcWS {
   // certificate estimator (k_cone_sub<1>): block of the most negative eigenvectors of Mchk, its Ritz values (of -Mchk), trace of MbufC
   int* sep_done;          // B: the separation vector of this harvested slot came from the tracked block (k_cone_sub<2>); NULL = feature off
   int cert_enable; double *XsC, *sub_thetaC, *trMc, *lb_est; int *sub_onC, *confirm;
+  // Shor mode (omc_shor_relax.hip): the big cone [Y X; X' Theta] is explicit, the column blocks are not used
+  int shor;               // 1: k_global takes the big cone's copy of Y (rx P0 + (1 - rx) Y + D0, leading dimension shN) instead of the column blocks
+  int shN;                // n + m
+  const double *shP0, *shD0;   // B * shN * shN
+  double clip_hi;         // upper clip of the cone kernels (1 for 0 <= Y <= I; 1e300 for the big cone's PSD projection)
+  double inv_s2;          // 1 / scale^2: the Shor solve runs on scale * A, objective and bound are reported unscaled (1 otherwise)
   int* sub_stat;          // B * 8: calls, power steps, failures (fall back to the full decomposition), seeds, failures by cause (too many positive Ritz values, step cap, Cholesky), Rayleigh-Ritz passes
   // rows
   int* R;                 // B

@@ -649,6 +649,8 @@ __device__ __forceinline__ double cone_M_entry(const OmcWS& w, int b, int mode, 
     return w.Mchk[(size_t)b * n * n + (size_t)j * n + i];
   } else if (mode == CONE_TOPK) {
     return w.Y[(size_t)b * n * n + (size_t)j * n + i];
+  } else if (mode == CONE_BIG) {
+    return w.Mbuf[(size_t)b * w.np16 * w.np16 + (size_t)j * w.np16 + i];
   } else {  // CONE_SEP: U U' - Y
     double s = 0.0;
     for (int t = 0; t < k; ++t) s += w.U[(size_t)b * n * k + (size_t)t * n + i] * w.U[(size_t)b * n * k + (size_t)t * n + j];
@@ -833,12 +835,13 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
       w.bx[(size_t)b * n + r] = s_w1 * s_sg1 * Gm[(size_t)s_i1 * ld + r] + s_w2 * s_sg2 * Gm[(size_t)s_i2 * ld + r];
     return;
   }
-  // CONE_CLIP01: W1 = V clip(lambda, 0, 1) V'.  Either rebuild the defect (lambda<0 or >1) on top of M, or the kept part.
+  // CONE_CLIP01 / CONE_BIG: W1 = V clip(lambda, 0, hi) V'.  Either rebuild the defect (lambda<0 or >hi) on top of M, or the kept part.
+  const double hi = w.clip_hi;
   if (tid == 0) {
     int ndef = 0, nkeep = 0;
     for (int t = 0; t < N; ++t) {
       double lamv = sqrt(ev[t]) - sigma;
-      if (lamv < 0.0 || lamv > 1.0) ++ndef;
+      if (lamv < 0.0 || lamv > hi) ++ndef;
       if (lamv > 0.0) ++nkeep;
     }
     int c = 0;
@@ -846,13 +849,13 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
       for (int t = 0; t < N; ++t) {
         double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
         if (lamv < 0.0) { sel[c] = t; wgt[c] = -lamv / nu2; ++c; }
-        else if (lamv > 1.0) { sel[c] = t; wgt[c] = -(lamv - 1.0) / nu2; ++c; }
+        else if (lamv > hi) { sel[c] = t; wgt[c] = -(lamv - hi) / nu2; ++c; }
       }
       s_base = 1.0;
     } else {
       for (int t = 0; t < N; ++t) {
         double nu2 = ev[t], lamv = sqrt(nu2) - sigma;
-        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, 1.0) / nu2; ++c; }
+        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, hi) / nu2; ++c; }
       }
       s_base = 0.0;
     }
@@ -1083,11 +1086,12 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   double* lamv_s = (double*)(sel + Np + (Np & 1));
   for (int t = tid; t < N; t += T) lamv_s[t] = sqrt(ev[t]) - sigma;
   __syncthreads();
+  const double hi = w.clip_hi;
   if (tid == 0) {
     int ndef = 0, nkeep = 0;
     for (int t = 0; t < N; ++t) {
       const double lamv = lamv_s[t];
-      if (lamv < 0.0 || lamv > 1.0) ++ndef;
+      if (lamv < 0.0 || lamv > hi) ++ndef;
       if (lamv > 0.0) ++nkeep;
     }
     s_nkeep = nkeep;
@@ -1097,13 +1101,13 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
       for (int t = 0; t < N; ++t) {
         const double lamv = lamv_s[t];
         if (lamv < 0.0) { sel[c] = t; wgt[c] = -lamv; ++c; }
-        else if (lamv > 1.0) { sel[c] = t; wgt[c] = -(lamv - 1.0); ++c; }
+        else if (lamv > hi) { sel[c] = t; wgt[c] = -(lamv - hi); ++c; }
       }
       s_base = 1.0;
     } else {
       for (int t = 0; t < N; ++t) {
         const double lamv = lamv_s[t];
-        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, 1.0); ++c; }
+        if (lamv > 0.0) { sel[c] = t; wgt[c] = fmin(lamv, hi); ++c; }
       }
       s_base = 0.0;
     }
@@ -1896,7 +1900,10 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     const int i = e % n, j = e / n;
     if (i < j) continue;
     double y = Y[e];
-    tY[TRIX(i, j)] = rho_f * w.Ncnt[e] * y + rho * (rx * W1[e] + (1.0 - rx) * y + D1[e]) + rho * (y + (1.0 - rx) * D3[e] + rx * E3[e]);
+    // Shor mode: the third copy of Y is the big cone's (over-relaxed projection + its scaled dual) instead of the column blocks
+    const double first = w.shor ? rho * (rx * w.shP0[(size_t)b * w.shN * w.shN + (size_t)j * w.shN + i] + (1.0 - rx) * y + w.shD0[(size_t)b * w.shN * w.shN + (size_t)j * w.shN + i])
+                                : rho_f * w.Ncnt[e] * y;
+    tY[TRIX(i, j)] = first + rho * (rx * W1[e] + (1.0 - rx) * y + D1[e]) + rho * (y + (1.0 - rx) * D3[e] + rx * E3[e]);
   }
   for (int e = tid; e < r * k; e += T) {
     int a = e % r, j = e / r;
@@ -1904,7 +1911,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   }
   for (int e = tid; e < R; e += T) mu[e] = lam[e] / rho;
   __syncthreads();
-  mfma_LLt(lamD, n, m, [&](int i, int j, double v) { tY[TRIX(i, j)] += 0.5 * g * v; });      // one wave owns a tile: deterministic
+  if (!w.shor) mfma_LLt(lamD, n, m, [&](int i, int j, double v) { tY[TRIX(i, j)] += 0.5 * g * v; });      // one wave owns a tile: deterministic
   __syncthreads();
   for (int e = tid; e < n * n; e += T) {
     const int i = e % n, j = e / n;
@@ -2189,11 +2196,11 @@ __global__ void k_check_final(OmcWS w, int last, int phase) {
   if (phase == 0 && w.confirm[b]) return;
   if (phase == 1 && !w.confirm[b]) return;
   const bool est = (phase == 0);
-  const double lbv = w.c0[b] + w.evsum[b] - w.cpen[b] + w.cst[b];
+  const double lbv = (w.c0[b] + w.evsum[b] - w.cpen[b] + w.cst[b]) * w.inv_s2;      // Shor mode solves for scale * A: values are reported unscaled
   const double lb_rig = w.lb[b];
   const double lb_dec = fmax(est ? fmax(lb_rig, w.lb_est[b]) : lb_rig, lbv);      // the bound the decisions of this check use
-  const double obj = w.obj[b];
-  const double Nk = (double)(w.n + w.k);
+  const double obj = w.obj[b] * w.inv_s2;
+  const double Nk = (double)(w.n + w.k + (w.shor ? w.m : 0));
   const bool feas = w.rp[b] <= w.eps_feas * sqrt(Nk) && !w.rowov[b];   // rows deferred by the NNQP cap: not a feasible point
   int term = -1;
   int stall_new = w.stall[b], votes_new = w.slow_votes[b];
