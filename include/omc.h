@@ -162,14 +162,19 @@ int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int*
  *               minors" -- what the reference's driver always passes (OMC.jl:656-673, 2508-2517) -- without shipping n*m pairs per node.
  * Nodes with identical lists share one index structure on the device (the static mode hands every node the same list).
  * Everything else as omc_relax_stage; then omc_relax_solve / omc_relax_submit / _wait and omc_relax_fetch as usual (X and Theta are
- * the explicit variables of the Shor program), plus omc_relax_fetch_shor for W (OMC.jl:1908; V1, V2, V3 are not returned: the driver
- * never reads them).  Status, objective (recomputed as OMC.jl:1960-1967 does) and the certified dual bound as in the base mode.
+ * the explicit variables of the Shor program), plus omc_relax_fetch_shor for W (OMC.jl:1908) and omc_relax_fetch_shor_V for V1, V2, V3.  Status, objective (recomputed as OMC.jl:1960-1967 does) and the certified dual bound as in the base mode.
  * rank k > 1 (Xt, Wt, H: OMC.jl:1526-1551, 1780-1827) returns OMC_ERR_UNSUPPORTED. */
 int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
                          const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
                          const double* U_upper, const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc,
                          const int64_t* soc_idx);
 int omc_relax_fetch_shor(omc_instance* h, double* W /* n*m per node, may be NULL */);
+/* The lifted products the order-5 blocks use (results["V1"], ["V2"], ["V3"], OMC.jl:1909-1911, restricted to the entries that occur in a
+ * block): 5 doubles per minor, in the node's minor order -- V1[i1,(j1,j2)], V1[i2,(j1,j2)], V2[(i1,i2),j1], V2[(i1,i2),j2],
+ * V3[(i1,i2),(j1,j2)] -- nodes concatenated with stride 5 * max_b n_shor[b].  Kept only when requested BEFORE staging
+ * (omc_set_shor_keep_V(h, 1): the copy costs 40 bytes per minor and node). */
+int omc_set_shor_keep_V(omc_instance* h, int keep);
+int omc_relax_fetch_shor_V(omc_instance* h, double* V);
 int omc_relax_batch_shor(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
                          const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
                          const double* U_upper, const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc,

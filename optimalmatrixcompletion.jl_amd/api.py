@@ -107,7 +107,7 @@ class Engine:
                                              _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(lo), _lib.ptr(hi)))
         self._B = B
 
-    def stage_shor(self, nodes, shor_info, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None, penalties=None):
+    def stage_shor(self, nodes, shor_info, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None, penalties=None, keep_V=False):
         """Stage a batch with add_Shor_valid_inequalities = true (OMC.jl:747-754 with node.Shor_info).  shor_info[b] =
         (constraints_indexes, SOC_constraints_indexes): 1-based (i1, i2, j1, j2) tuples and 1-based (i, j) pairs as the reference
         holds them (OMC.jl:37-40); SOC_constraints_indexes = None means "every coordinate outside the minors" (what the reference's
@@ -115,6 +115,8 @@ class Engine:
         n, k = self.n, self.k
         if len(shor_info) != len(nodes):
             raise ValueError("one Shor_info per node")
+        _lib.check(self._lib.omc_set_shor_keep_V(self._h, 1 if keep_V else 0))
+        self._nqmax = max([len(np.asarray(mi).reshape(-1, 4)) for (mi, _) in shor_info] + [1])
         if penalties is not None:
             _lib.check(self._lib.omc_set_shor_penalties(self._h, float(penalties[0]), float(penalties[1]), float(penalties[2])))
         L, cx, cU, cd = _pack_cuts(nodes, n, k, disjunctive_cuts_type)
@@ -147,6 +149,12 @@ class Engine:
         W = np.zeros((self._B, self.n * self.m))
         _lib.check(self._lib.omc_relax_fetch_shor(self._h, _lib.ptr(W)))
         return [W[b].reshape((self.n, self.m), order="F") for b in range(self._B)]
+
+    def fetch_shor_V(self):
+        """(nq_max, 5) per node: V1[i1,(j1,j2)], V1[i2,(j1,j2)], V2[(i1,i2),j1], V2[(i1,i2),j2], V3 of every minor (needs keep_V at staging)."""
+        V = np.zeros((self._B, self._nqmax * 5))
+        _lib.check(self._lib.omc_relax_fetch_shor_V(self._h, _lib.ptr(V)))
+        return [V[b].reshape(self._nqmax, 5) for b in range(self._B)]
 
     def solve(self):
         _lib.check(self._lib.omc_relax_solve(self._h))
@@ -188,18 +196,21 @@ class Engine:
 
     def matrix_completion_SDP_relaxation(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None,
                                          want_Y=True, want_X=True, want_Theta=False, rho_scales=None, add_Shor_valid_inequalities=False,
-                                         shor_info=None, shor_penalties=None):
+                                         shor_info=None, shor_penalties=None, want_V=False):
         """Batch form of OMC.jl:1431-1943 (use_disjunctive_cuts = true).  `nodes` = list of cut lists; with
         add_Shor_valid_inequalities = True, `shor_info` = one (constraints_indexes, SOC_constraints_indexes) pair per node and
         every result also carries "W" (OMC.jl:1907-1908)."""
         if add_Shor_valid_inequalities:
             if shor_info is None:
                 raise ValueError("add_Shor_valid_inequalities = true needs node.Shor_info (OMC.jl:1508)")
-            self.stage_shor(nodes, shor_info, disjunctive_cuts_type, params, U_lower, U_upper, shor_penalties)
+            self.stage_shor(nodes, shor_info, disjunctive_cuts_type, params, U_lower, U_upper, shor_penalties, keep_V=want_V)
             self.solve()
             out = self.fetch(want_Y, want_X, want_Theta)
             for r, Wb in zip(out, self.fetch_shor()):
                 r["W"] = Wb
+            if want_V:
+                for r, Vb, (mi, _) in zip(out, self.fetch_shor_V(), shor_info):
+                    r["V"] = Vb[:len(np.asarray(mi).reshape(-1, 4))]
             return out
         self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper, rho_scales)
         self.solve()

@@ -175,7 +175,11 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                      altmin_flag=True, max_altmin_probability=1.0, min_altmin_probability=0.005,
                      altmin_probability_decay_rate=1.1, use_max_steps=False, max_steps=1000000, time_limit=3600.0,
                      batch=64, rho_scale=None, params=None, seed=0, use_certified_bound=True, verbose=False,
-                     rank=0, world_size=1, altmin_root_n_iters=1, accel=1):
+                     rank=0, world_size=1, altmin_root_n_iters=1, accel=1,
+                     add_Shor_valid_inequalities=False, Shor_valid_inequalities_noisy_rank1_num_entries_present=(1, 2, 3, 4),
+                     add_Shor_valid_inequalities_fraction=1.0, add_Shor_valid_inequalities_iterative=False,
+                     max_update_Shor_indices_probability=1.0, min_update_Shor_indices_probability=0.1,
+                     update_Shor_indices_probability_decay_rate=1.1, update_Shor_indices_n_minors=100, shor_params=None):
     """Behavioural counterpart of the reference driver for use_disjunctive_cuts = true, no Shor, one altmin run at the
     root (altmin_root_n_iters = 1).  Differences, all deliberate: (1) up to `batch` nodes are popped per round in the
     reference's selection order and relaxed in ONE GPU batch (batch=1 reproduces the serial order); (2) the node bound
@@ -184,7 +188,12 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     key = parent objective, ties by node id; (4) numpy's RNG replaces Julia's for the altmin coin flips (OMC.jl:867).
     With world_size > 1 every rank runs the same host logic on the same tree, relaxes its round-robin shard of the popped nodes
     and the ranks exchange (class Comm) the small per-node records, a MIN all-reduce of the incumbent and -- only when it improved --
-    the incumbent X from its owner; leaving the loop is decided collectively.  (5) A master-feasible node updates the incumbent with
+    the incumbent X from its owner; leaving the loop is decided collectively.
+    add_Shor_valid_inequalities (rank 1, one rank): every node carries node.Shor_info (OMC.jl:37-40).  Static mode (OMC.jl:646-669): the
+    class lists of generate_rank1_matrix_completion_Shor_constraints_indexes (on the device), thinned by the fraction with numpy's RNG
+    (randsubseq, OMC.jl:652-655); iterative mode (OMC.jl:670-674, 956-967, 2495-2518): the root starts without minors and a split node
+    adds, with probability p(depth), the update_Shor_indices_n_minors most violated minors of its X (generate_violated_Shor_minors on
+    the device) to the list its children inherit.  The SOC list is always "every coordinate outside the minors" (OMC.jl:656-665, 2508-2517).  (5) A master-feasible node updates the incumbent with
     evaluate_objective of the rank-k projection of its X, a certified value, instead of the relaxation objective (OMC.jl:818-828).
     Returns (solution, instance) dicts with the reference's key names where they apply (OMC.jl:604-621, 391-454)."""
     import heapq
@@ -201,6 +210,24 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     if engine.k > 4 and altmin_flag:
         raise NotImplementedError("GPU altmin supports rank k <= 4; pass altmin_flag=False beyond that")
     rng = np.random.default_rng(seed)                                                      # OMC.jl:333 (Random.seed!(0))
+    shor = bool(add_Shor_valid_inequalities)
+    shor_classes = [int(c) for c in Shor_valid_inequalities_noisy_rank1_num_entries_present]
+    if shor:
+        if k != 1:
+            raise NotImplementedError("Shor mode is built for rank 1 (the k > 1 form, OMC.jl:1526-1551, is not)")
+        if world_size != 1:
+            raise NotImplementedError("Shor mode of the driver counterpart runs on one rank (the violated-minor update needs the node's X)")
+        if not 0.0 <= add_Shor_valid_inequalities_fraction <= 1.0:
+            raise ValueError("Argument `add_Shor_valid_inequalities_fraction` out of bounds [0.0, 1.0].")          # OMC.jl:256-263
+        if add_Shor_valid_inequalities_iterative:
+            if not 0.0 <= max_update_Shor_indices_probability <= 1.0:
+                raise ValueError("Argument `max_update_Shor_indices_probability` out of bounds [0.0, 1.0].")       # OMC.jl:297-303
+            if not 0.0 < min_update_Shor_indices_probability < 1.0:
+                raise ValueError("Argument `min_update_Shor_indices_probability` out of bounds (0.0, 1.0).")       # OMC.jl:304-310
+            if not 1.0 < update_Shor_indices_probability_decay_rate:
+                raise ValueError("Argument `update_Shor_indices_probability_decay_rate` out of bounds (1.0, inf).")   # OMC.jl:311-317
+            if not 1 <= update_Shor_indices_n_minors:
+                raise ValueError("Argument `update_Shor_indices_n_minors` out of bounds [1.0, inf).")              # OMC.jl:318-324
     start = time.time()
     counters = dict(nodes_explored=0, nodes_total=1, nodes_dominated=0, nodes_relax_infeasible=0, nodes_relax_feasible=0,
                     nodes_relax_feasible_pruned=0, nodes_master_feasible=0, nodes_master_feasible_improvement=0,
@@ -231,6 +258,8 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                     Y_initial=U_init @ U_init.T, MSE_in_initial=mse0["in"], MSE_out_initial=mse0["out"], MSE_all_initial=mse0["all"],
                     objective=ub, X=X0, U=U_init, Y=U_init @ U_init.T, objective_time_found=time.time() - start)   # OMC.jl:604-621
     precomputed = {}
+    if shor and rho_scale is None:
+        rho_scale = 1.0                      # the Shor splitting has its own (scaled) penalties: no autotune
     if rho_scale is None:
         rho_scale, _, root_res = autotune_rho_scale(engine, disjunctive_cuts_type, return_result=True,
                                                     breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints])
@@ -239,8 +268,21 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     # Anderson acceleration is ON in the driver: on trees that really branch it halves the iterations per node (README instance: 263 -> 407
     # nodes/s, tools/gpu_bnb_cfg1.py); the library default stays off because the degenerate frontier of the bench instance rejects most points
     P = params or default_params(rho_scale=float(rho_scale), breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints], accel=int(accel))
+    if shor:
+        # 1e-5 is the tolerance SURVEY 8c states for the Shor configurations; the splitting needs a few thousand iterations per node
+        PS = shor_params or default_params(rho_scale=1.0, breakpoints=BREAKPOINTS[disjunctive_cuts_breakpoints], eps_gap=1e-5, max_iters=8000)
+        if add_Shor_valid_inequalities_iterative:
+            root_minors = np.zeros((0, 4), np.int64)                                       # OMC.jl:670-674
+        else:
+            root_minors = np.asarray(engine.generate_rank1_matrix_completion_Shor_constraints_indexes(shor_classes), np.int64).reshape(-1, 4)
+            if add_Shor_valid_inequalities_fraction < 1.0:                                 # randsubseq, OMC.jl:652-655
+                root_minors = root_minors[rng.random(len(root_minors)) < add_Shor_valid_inequalities_fraction]
+        shor_decay_depth = (math.log(max_update_Shor_indices_probability / min_update_Shor_indices_probability, update_Shor_indices_probability_decay_rate)
+                            if add_Shor_valid_inequalities_iterative else 0.0)
     # ---- tree ------------------------------------------------------------------------------------------------
     nodes = {1: dict(cuts=[], LB=-math.inf, depth=0, parent=0)}
+    if shor:
+        nodes[1]["shor"] = root_minors
     heap = [(math.inf, 1)]            # (key = parent objective, node id)   OMC.jl:697
     fifo = [1]
     lb = -math.inf
@@ -299,8 +341,13 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
             t0 = time.time()
             mine = todo[rank::world_size] if world_size > 1 else todo                        # round-robin in queue order
             need = [(nid, nd) for nid, nd in mine if nid not in precomputed]
-            fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=P,
-                                                            want_X=True) if need else []
+            if shor:
+                fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=PS, want_X=True,
+                                                                add_Shor_valid_inequalities=True,
+                                                                shor_info=[(nd["shor"], None) for _, nd in need]) if need else []
+            else:
+                fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=P,
+                                                                want_X=True) if need else []
             fresh = {nid: r for (nid, _), r in zip(need, fresh)}
             local = {nid: (precomputed.pop(nid) if nid in precomputed else fresh[nid]) for nid, _ in mine}
             # ---- exchange of the small per-node records (no X, no Y) ------------------------------------------------
@@ -370,10 +417,22 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                 counters["nodes_relax_feasible_split"] += 1
                 r = dict(breakpoint_vec=row[6:6 + n].copy(), U=row[6 + n:].reshape((n, k), order="F").copy())
                 kids = make_children(nd["cuts"], r, disjunctive_cuts_type, k)
+                child_shor = nd.get("shor")
+                if shor and add_Shor_valid_inequalities_iterative:                          # OMC.jl:956-967, 2495-2518
+                    pu = (min_update_Shor_indices_probability if nd["depth"] > shor_decay_depth
+                          else max_update_Shor_indices_probability / (update_Shor_indices_probability_decay_rate ** nd["depth"]))
+                    if rng.random() < pu:
+                        new = engine.generate_violated_Shor_minors(local[nid]["X"][None, :, :], shor_classes, [tuple(t) for t in child_shor.tolist()],
+                                                                   int(update_Shor_indices_n_minors))
+                        add = np.asarray([t for _, t in new], np.int64).reshape(-1, 4)
+                        child_shor = np.concatenate([child_shor, add]) if len(add) else child_shor     # union (2504-2507): `new` excludes the existing ones
+                        counters["shor_updates"] = counters.get("shor_updates", 0) + 1
                 for cuts in kids:
                     counters["nodes_total"] += 1
                     cid = counters["nodes_total"]
                     nodes[cid] = dict(cuts=cuts, LB=nd["LB"], depth=nd["depth"] + 1, parent=nid)
+                    if shor:
+                        nodes[cid]["shor"] = child_shor
                     heapq.heappush(heap, (nd["LB"], cid)); fifo.append(cid)
         # prune dominated nodes (OMC.jl:1220-1244) and update the global lower bound (OMC.jl:1207-1218)
         for nid in [i for i, nd in nodes.items() if nd["LB"] > ub]:

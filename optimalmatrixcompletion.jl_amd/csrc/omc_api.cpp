@@ -93,7 +93,7 @@ struct omc_instance {
   double shor_last_ms = 0; long long shor_last_candidates = 0;
   // Shor-mode relaxation (omc_relax_stage_shor): index structures of the distinct lists, explicit X / W / Theta state, view of the workspace
   // through which the base eigen-kernels project the order-(n+m) cone
-  bool shor_req = false, shor_on = false; double shor_rho = 0.05, shor_r4 = 20.0, shor_r5 = 2.0;
+  bool shor_req = false, shor_on = false, shor_keep_V = false; DevBuf soV; double shor_rho = 0.05, shor_r4 = 20.0, shor_r5 = 2.0;
   ShWS sh{}; OmcWS wbig{}; int big_lpp = 0, big_use_lds = 0, big_cone_lds_ok = 0; size_t big_lds = 0, big_cone_lds = 0;
   DevBuf sgInts, sgBytes, sgGroups, sgNodeGroup, sAh, sX, sW, sTh, sV1, sV2, sV3, sD0, sP0, sMbufB, sVrowB, sTq, sPq, sNq, sD5x, sD5t, snu5, sP5x,
       scolpart, sminpart, sminpart2, sfroB, svvB, se1, se2, soX, soW, soTh, sbigscr;
@@ -221,7 +221,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt,
                    &h->sgInts, &h->sgBytes, &h->sgGroups, &h->sgNodeGroup, &h->sAh, &h->sX, &h->sW, &h->sTh, &h->sV1, &h->sV2, &h->sV3, &h->sD0, &h->sP0, &h->sMbufB, &h->sVrowB,
                    &h->sTq, &h->sPq, &h->sNq, &h->sD5x, &h->sD5t, &h->snu5, &h->sP5x, &h->scolpart, &h->sminpart, &h->sminpart2, &h->sfroB, &h->svvB, &h->se1, &h->se2,
-                   &h->soX, &h->soW, &h->soTh, &h->sbigscr};
+                   &h->soX, &h->soW, &h->soTh, &h->sbigscr, &h->soV};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1220,6 +1220,8 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   sh.e1 = h->se1.as<double>(); sh.e2 = h->se2.as<double>();
   sh.objcol = w.objcol; sh.c0col = w.c0col; sh.lamDX = w.lamDX;
   sh.oX = h->soX.as<double>(); sh.oW = h->soW.as<double>(); sh.oTh = h->soTh.as<double>();
+  sh.oV = nullptr;
+  if (h->shor_keep_V) { ENS(h->soV, sN * 5 * nq1 * 8); HIPCHK(hipMemsetAsync(h->soV.p, 0, sN * 5 * nq1 * 8, s)); sh.oV = h->soV.as<double>(); }
   // ---- base workspace in Shor mode, and the view through which its eigen-kernels project the order-(n+m) cone -------------------------
   w.shor = 1; w.shN = N; w.shP0 = sh.P0; w.shD0 = sh.D0; w.inv_s2 = 1.0 / (sc * sc);
   OmcWS& wb = h->wbig;
@@ -1255,6 +1257,22 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   HIPCHK(hipStreamSynchronize(s));
   h->shor_on = true;
   h->staged = true;
+  return 0;
+}
+
+int omc_set_shor_keep_V(omc_instance* h, int keep) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  h->shor_keep_V = keep != 0;
+  return 0;
+}
+
+int omc_relax_fetch_shor_V(omc_instance* h, double* V) {
+  if (!h || !h->staged || !h->shor_on) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch_shor_V: no Shor-mode batch staged");
+  if (!h->sh.oV) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch_shor_V: V was not kept (call omc_set_shor_keep_V(h, 1) before staging)");
+  if (!V) return fail(OMC_ERR_ARGUMENT, "V is NULL");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpyAsync(V, h->sh.oV, 8 * (size_t)h->sh.Btot * 5 * (size_t)std::max(h->sh.nqmax, 1), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 

@@ -46,6 +46,7 @@ struct ShWS {
   double *e1, *e2;                              // S * nv1max, S * nv2max: certificate: V residual per key
   double *objcol, *c0col, *lamDX;               // base certificate inputs (S*m, S*m, S*m*n)
   double *oX, *oW, *oTh;                        // Btot * (n*m, n*m, m*m)
+  double* oV;                                   // Btot * 5 * nqmax (NULL: not kept): V1a, V1b, V2a, V2b, V3 per minor
 };
 
 #ifdef __cplusplus

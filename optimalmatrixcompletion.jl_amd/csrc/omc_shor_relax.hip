@@ -620,6 +620,13 @@ __global__ void __launch_bounds__(SH_T) k_shor_harvest(ShWS w) {
     sw += wv;
   }
   for (int jp = tid; jp < m; jp += T) w.oTh[(size_t)nb * m * m + (size_t)j * m + jp] = w.Th[(size_t)b * m * m + (size_t)j * m + jp] * is2;
+  if (w.oV) {      // the lifted products of the blocks, unscaled, in the node's minor order
+    const double* V1 = w.V1 + (size_t)b * w.nv1max; const double* V2 = w.V2 + (size_t)b * w.nv2max; const double* V3 = w.V3 + (size_t)b * w.nqmax;
+    for (int q = j * T + tid; q < G.nq; q += m * T) {
+      double* o = w.oV + ((size_t)nb * w.nqmax + q) * 5;
+      o[0] = V1[G.kid[q]] * is2; o[1] = V1[G.kid[G.nq + q]] * is2; o[2] = V2[G.kid[2 * G.nq + q]] * is2; o[3] = V2[G.kid[3 * G.nq + q]] * is2; o[4] = V3[q] * is2;
+    }
+  }
   sw = block_sum(sw, red);
   if (tid == 0) {
     const int sr = G.slackrow[j];
