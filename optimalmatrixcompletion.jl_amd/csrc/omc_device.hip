@@ -1482,6 +1482,22 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
     // lambda_min(U U' - Y) = -theta_1; canonical sign (largest-magnitude entry positive) and the smallest_2 mix of OMC.jl:2471-2476
     const int i1 = sel[0], i2 = sel[1];
     __shared__ double s_sg[2], s_wt[2];
+    // A small residual shows that (theta_1, x_1) is AN eigenpair of Y - U U', not that it is the extreme one: the block was seeded from
+    // another matrix (Y - D1).  Rigorous guard: every eigenvalue outside the block is at most rem = sqrt(||M||_F^2 - sum theta^2) in
+    // magnitude, so the pair is the largest one only if rem < theta_1 (and theta_2 likewise for smallest_2_eigvec).  A result that would
+    // declare the node master-feasible (lambda_min >= -1e-6, OMC.jl:1274-1276: the node is fathomed on it) is never taken from the
+    // block either.  In both cases sep_done stays 0 and the cold eigendecomposition (CONE_SEP) decides.
+    __shared__ int s_acc;
+    if (tid == 0) {
+      double s2 = 0.0;
+      for (int t = 0; t < SUBP; ++t) s2 += th[t] * th[t];
+      const double rem = sqrt(fmax(fro2 - s2, 0.0)) + 1e-12 * nF;
+      bool acc = (-th[i1] < -1e-6) && rem < th[i1];
+      if (w.breakpoints == 2) acc = acc && rem < fmax(th[i2], 1e-10);
+      s_acc = acc ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_acc) return;
     if (tid == 0) {
       const double l1 = -th[i1], l2 = -th[i2];
       w.lmin[2 * b] = l1; w.lmin[2 * b + 1] = l2;

@@ -787,3 +787,121 @@ def test_asynchronous_submit_poll_wait(have_gpu, omc, orc):
         assert a["status_code"] == b["status_code"] and a["iters"] == b["iters"]
         assert a["objective"] == b["objective"] and a["dual_bound"] == b["dual_bound"]
     eng.close()
+
+
+# ---- round 3: tightened parity ("weak: parity") ---------------------------------------------------------------------------
+def test_config2_full_size_depth3_cut_node_matches_oracle(have_gpu, omc, orc):
+    """BASELINE config 2 at the size the metric is quoted on (100 x 100, rank 1, 20 % observed): a depth-3 cut node against the oracle at
+    2e-6 (the oracle takes about a minute per solve here; the path is built from GPU results so that it is paid for once)."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(2, seed=0)
+    inst = orc.Instance(A, mask, gamma, 1)
+    eng = omc.Engine(A, mask, gamma, 1)
+    P = omc.default_params(rho_scale=4.0)
+    cuts = []
+    for d in range(3):
+        r = eng.matrix_completion_SDP_relaxation([cuts], "linear", params=P, want_X=False)[0]
+        assert r["feasible"]
+        cuts = cuts + [(r["breakpoint_vec"].copy(), r["U"].copy(), ["left" if d % 2 == 0 else "right"])]
+    g = eng.matrix_completion_SDP_relaxation([cuts], "linear", params=P)[0]
+    o = orc.sdp_relaxation(inst, cuts, "linear", params=orc.RelaxParams(rho_scale=4.0))
+    assert g["status_code"] == 0 and o["termination_status"] == orc.OMC_OPTIMAL
+    assert g["objective"] == pytest.approx(o["objective"], rel=OBJ_REL)
+    assert abs(g["objective"] - g["dual_bound"]) <= 1.01e-6 * abs(g["objective"])
+    rows = orc.build_rows(inst, cuts, "linear")
+    Theta = eng.matrix_completion_SDP_relaxation([cuts], "linear", params=P, want_Theta=True)[0]["Theta"]
+    res = orc.primal_residuals(inst, rows, g["Y"], g["U"], g["X"], Theta)
+    # the order-200 cone is dominated by Theta (||Theta||_2 ~ ||X||_F^2 ~ 1e4 here): its residual is judged relative to that
+    assert res["psd_YXTheta"] <= 1e-8 * np.linalg.norm(Theta, 2), res
+    assert max(v for kk, v in res.items() if kk not in ("max", "psd_YXTheta")) <= 2e-6, res
+    eng.close()
+
+
+def test_gpu_result_against_the_independent_slsqp_solve(have_gpu, omc, orc):
+    """The independent check of tests/test_oracle_kats.py (SLSQP over Y = uu' + RR' with the cut rows of OMC.jl:1580-1683 written out by
+    hand) applied to the GPU's result directly: every feasible value SLSQP reaches stays above the GPU's dual bound, and the converged
+    value equals the GPU's objective -- no oracle in between."""
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(7)
+    n, m, k = 5, 6, 1
+    A, mask = orc.make_instance(n, m, k, seed=41, kind="lowrank", n_indices=18, noise=0.3)
+    inst = orc.Instance(A, mask, GAMMA, k)
+    eng = omc.Engine(A, mask, GAMMA, k)
+    P = omc.default_params(rho_scale=8.0)
+    root = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P)[0]
+    x = root["breakpoint_vec"].copy()
+    cut = (x, root["U"].copy(), ["right"])
+    g = eng.matrix_completion_SDP_relaxation([[cut]], "linear", params=P)[0]
+    assert g["status_code"] in (0, 1)
+    vhat = float(root["U"][:, 0] @ x)
+    lo, hi, sl, ic = orc.cut_piece("linear", "right", vhat)
+    iu = np.tril_indices(n)
+
+    def unpack(z):
+        u = z[:n]; R = np.zeros((n, n)); R[iu] = z[n:]
+        return u, np.outer(u, u) + R @ R.T
+
+    cons = [
+        dict(type="ineq", fun=lambda z: 1.0 - np.trace(unpack(z)[1])),
+        dict(type="ineq", fun=lambda z: 1.0 - np.linalg.eigvalsh(unpack(z)[1])[-1]),
+        dict(type="ineq", fun=lambda z: 1.0 - float(z[:n] @ z[:n])),
+        dict(type="ineq", fun=lambda z: z[n - 1]),
+        dict(type="ineq", fun=lambda z: float(x @ z[:n]) - lo), dict(type="ineq", fun=lambda z: hi - float(x @ z[:n])),
+        dict(type="ineq", fun=lambda z: sl * float(x @ z[:n]) + ic - float(x @ unpack(z)[1] @ x)),
+    ]
+    best = np.inf
+    for trial in range(6):
+        u0 = g["U"][:, 0] + 0.05 * rng.standard_normal(n) if trial == 0 else 0.3 * rng.standard_normal(n)
+        z0 = np.concatenate([u0, 0.2 * rng.standard_normal(len(iu[0]))])
+        res = minimize(lambda z: inst.f_value(unpack(z)[1]), z0, constraints=cons, bounds=[(-1, 1)] * n + [(None, None)] * len(iu[0]), method="SLSQP",
+                       options=dict(ftol=1e-13, maxiter=500))
+        if all(cn["fun"](res.x) >= -1e-8 for cn in cons):
+            assert g["dual_bound"] <= res.fun + 1e-7 * abs(res.fun)
+            best = min(best, res.fun)
+    assert np.isfinite(best)
+    if g["status_code"] == 0:
+        assert g["objective"] == pytest.approx(best, rel=2e-5)
+    eng.close()
+
+
+def test_separation_from_the_tracked_block_agrees_with_the_cold_eigendecomposition(have_gpu, omc, orc):
+    """the separation vector of a harvested slot may come from the tracked block (k_cone_sub<2>), which only proves that its pair
+    is AN eigenpair of Y - UU'.  On a pure-noise instance (README type: Y - UU' keeps many significant eigenvalues) and on a low-rank one,
+    every node of a depth-4 frontier is checked against omc_separation_batch (cold eigendecomposition of the returned (Y, U)): same
+    lambda_min, same vector up to the eigen-gap, and no node is called master-feasible by one path and not by the other."""
+    for kind, n, m, nidx, rs in (("readme", 60, 64, None, 16.0), ("lowrank", 64, 72, 1400, 4.0)):
+        A, mask = orc.make_instance(n, m, 1, n_indices=nidx, seed=3, noise=0.1, kind=kind)
+        eng = omc.Engine(A, mask, GAMMA, 1)
+        P = omc.default_params(rho_scale=rs, max_iters=1500)
+        nodes, _ = omc.pkg.bnb.expand_frontier(eng, 4, "linear", params=P)
+        out = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_X=False)
+        ok = [o for o in out if o["feasible"]]
+        xs, lam, _ = eng.breakpoint_vectors([o["Y"] for o in ok], [o["U"] for o in ok])
+        for o, xc, lc in zip(ok, xs, lam):
+            assert o["lambda_min"][0] == pytest.approx(lc[0], abs=1e-7)
+            assert (o["lambda_min"][0] >= -1e-6) == (lc[0] >= -1e-6)
+            if lc[1] - lc[0] > 1e-4:                       # a simple eigenvalue: the vector is determined up to its (canonical) sign
+                assert np.allclose(o["breakpoint_vec"], xc, atol=1e-5)
+        eng.close()
+
+
+def test_stalled_nodes_certified_at_the_relaxed_residual_pass_the_primal_residuals(have_gpu, omc, orc):
+    """a node whose values have been stationary for `stall_checks` checks is still reported OPTIMAL when its two-sided gap
+    is closed and its cone residual is within 10x of eps_feas sqrt(n + k) (k_check_final).  Whatever path certified a node, the returned
+    point must pass the reference's rows and cones at the tolerance the certificate claims."""
+    A, mask = orc.make_instance(20, 24, 1, seed=11, kind="readme")
+    inst = orc.Instance(A, mask, GAMMA, 1)
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    P = omc.default_params(rho_scale=16.0, stall_checks=4)          # a short stall window makes the relaxed path fire
+    nodes, _ = omc.pkg.bnb.expand_frontier(eng, 4, "linear", params=P)
+    out = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_Theta=True)
+    nopt = 0
+    for cuts, o in zip(nodes, out):
+        if o["status_code"] != 0:
+            continue
+        nopt += 1
+        rows = orc.build_rows(inst, cuts, "linear")
+        res = orc.primal_residuals(inst, rows, o["Y"], o["U"], o["X"], o["Theta"])
+        assert res["max"] <= 10 * 1e-7 * np.sqrt(21) * 1.5, res            # 10 x eps_feas sqrt(n + k), with slack for the recovery of U
+        assert abs(o["objective"] - o["dual_bound"]) <= 1.01e-6 * max(1.0, abs(o["objective"]))
+    assert nopt >= len(nodes) // 2
+    eng.close()
