@@ -284,7 +284,9 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     if shor:
         nodes[1]["shor"] = root_minors
     heap = [(math.inf, 1)]            # (key = parent objective, node id)   OMC.jl:697
+    lbheap = [(-math.inf, 1)]         # (node bound, node id), lazy deletion: the global lower bound is its smallest live entry (OMC.jl:1207-1218)
     fifo = [1]
+    ub_at_last_prune = math.inf
     lb = -math.inf
     now_gap = math.inf
     t_relax = t_altmin = 0.0
@@ -405,7 +407,9 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
             # ---- incumbent: 16-byte MIN all-reduce; X travels only when the incumbent improved ---------------------------
             my_ub = min([c[0] for c in cand], default=math.inf)
             src = min(cand, key=lambda c: c[0])[2] if cand else "altmin"
-            g_ub, g_src, owner = comm.min_bounds(my_ub, 0.0 if src == "master" else 1.0)     # second slot: which kind of node found it (ties: master)
+            g_ub, _, owner = comm.min_bounds(my_ub, 0.0)
+            # which kind of node found it: only ranks whose candidate IS the global minimum vote (ties: master); the others send 2
+            _, g_src, _ = comm.min_bounds(my_ub, (0.0 if src == "master" else 1.0) if (cand and my_ub == g_ub) else 2.0)
             if g_ub < ub:
                 Xl = min(cand, key=lambda c: c[0])[1] if (cand and comm.rank == owner) else np.zeros((n, m))
                 Xl = comm.bcast_matrix(Xl, owner)
@@ -433,12 +437,18 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                     nodes[cid] = dict(cuts=cuts, LB=nd["LB"], depth=nd["depth"] + 1, parent=nid)
                     if shor:
                         nodes[cid]["shor"] = child_shor
-                    heapq.heappush(heap, (nd["LB"], cid)); fifo.append(cid)
-        # prune dominated nodes (OMC.jl:1220-1244) and update the global lower bound (OMC.jl:1207-1218)
-        for nid in [i for i, nd in nodes.items() if nd["LB"] > ub]:
-            del nodes[nid]
-        if nodes:
-            minval = min(nd["LB"] for nd in nodes.values())
+                    heapq.heappush(heap, (nd["LB"], cid)); heapq.heappush(lbheap, (nd["LB"], cid)); fifo.append(cid)
+        # prune dominated nodes (OMC.jl:1220-1244): the open set can only gain dominated nodes when the incumbent improved, so the scan the
+        # reference repeats every iteration runs only then; the global lower bound (OMC.jl:1207-1218) is the smallest live entry of a
+        # lazy-deletion heap keyed by the node bounds (a child's bound is fixed when it is created)
+        if ub < ub_at_last_prune:
+            for nid in [i for i, nd in nodes.items() if nd["LB"] > ub]:
+                del nodes[nid]
+            ub_at_last_prune = ub
+        while lbheap and (lbheap[0][1] not in nodes or nodes[lbheap[0][1]]["LB"] != lbheap[0][0]):
+            heapq.heappop(lbheap)
+        if nodes and lbheap:
+            minval = lbheap[0][0]
             if minval > lb:
                 lb = minval
         now_gap = compute_gap(lb, ub)

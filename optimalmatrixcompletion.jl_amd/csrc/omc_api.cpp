@@ -731,6 +731,7 @@ int omc_relax_solve(omc_instance* h) {
   // captured again only when the number of live slots changes.  Per-kernel HIP-event timing is not available inside a graph, so the
   // large batches that the bench times keep the eager path.
   const int graph_max = getenv("OMC_GRAPH_MAX") ? atoi(getenv("OMC_GRAPH_MAX")) : 16;      // measured: -6 % per iteration at batch 1, +8 % at 128 slots of order 200
+  const bool no_graph = getenv("OMC_NO_GRAPH") != nullptr;      // read once per solve, not per iteration
   hipGraphExec_t gexec[2] = {nullptr, nullptr}; int gexec_n = -1;
   struct GraphGuard { hipGraphExec_t* e; ~GraphGuard() { for (int q = 0; q < 2; ++q) if (e[q]) (void)hipGraphExecDestroy(e[q]); } } gguard{gexec};
   auto body = [&](int g, const OmcWS& wg, bool timed, bool with_aa) -> int {
@@ -781,7 +782,7 @@ int omc_relax_solve(omc_instance* h) {
     ++it;
     const bool is_check = (it % check == 0);
     if (multi && wait_main) HIPCHK(hipEventRecord(h->ev_main, s));
-    const bool use_graph = multi && G == 1 && use_list && nlist <= graph_max && !getenv("OMC_NO_GRAPH");
+    const bool use_graph = multi && G == 1 && use_list && nlist <= graph_max && !no_graph;
     for (int g = 0; g < G; ++g) {
       if (gact[g] == 0) continue;
       OmcWS wg = w; wg.b0 = gb0[g]; wg.nB = gnB[g];
