@@ -181,7 +181,8 @@ int omc_relax_batch_shor(omc_instance* h, int B, const omc_relax_params* params,
                          const int64_t* soc_idx, double* objective, double* dual_bound, int* status, int* iters, double* Y,
                          double* U, double* X, double* Theta, double* W, double* lambda_min, double* breakpoint_x,
                          double* solve_time);
-/* penalties of the Shor-mode splitting, in the scaled variables (defaults 0.05, 20, 2; params->rho_scale multiplies rho) */
+/* penalties of the Shor-mode splitting, in the scaled variables (defaults 0.05, 0 = automatic per list: 75 n m / (4 n_shor) clamped to
+ * [0.25, 40], 2; params->rho_scale multiplies rho) */
 int omc_set_shor_penalties(omc_instance* h, double rho, double r4, double r5);
 
 /* ---- alternating_minimization (OMC.jl:1979-2279), disjunctive mode, B problems at once, rank k <= 4 --------

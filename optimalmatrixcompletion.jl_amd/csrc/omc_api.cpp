@@ -93,10 +93,11 @@ struct omc_instance {
   double shor_last_ms = 0; long long shor_last_candidates = 0;
   // Shor-mode relaxation (omc_relax_stage_shor): index structures of the distinct lists, explicit X / W / Theta state, view of the workspace
   // through which the base eigen-kernels project the order-(n+m) cone
-  bool shor_req = false, shor_on = false, shor_keep_V = false; DevBuf soV; double shor_rho = 0.05, shor_r4 = 20.0, shor_r5 = 2.0;
+  bool shor_req = false, shor_on = false, shor_keep_V = false; DevBuf soV; double shor_rho = 0.05, shor_r4 = 0.0, shor_r5 = 2.0;      // r4 = 0: automatic per list
   ShWS sh{}; OmcWS wbig{}; int big_lpp = 0, big_use_lds = 0, big_cone_lds_ok = 0; size_t big_lds = 0, big_cone_lds = 0;
   DevBuf sgInts, sgBytes, sgGroups, sgNodeGroup, sAh, sX, sW, sTh, sV1, sV2, sV3, sD0, sP0, sMbufB, sVrowB, sTq, sPq, sNq, sD5x, sD5t, snu5, sP5x,
-      scolpart, sminpart, sminpart2, sfroB, svvB, se1, se2, soX, soW, soTh, sbigscr;
+      scolpart, sminpart, sminpart2, sfroB, svvB, se1, se2, soX, soW, soTh, sbigscr, sXsB, ssubSB, ssubIB;
+  long long big_sub_tot[8] = {0};
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
   size_t nnz_rows() const { return row_idx.size(); }
@@ -221,7 +222,7 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt,
                    &h->sgInts, &h->sgBytes, &h->sgGroups, &h->sgNodeGroup, &h->sAh, &h->sX, &h->sW, &h->sTh, &h->sV1, &h->sV2, &h->sV3, &h->sD0, &h->sP0, &h->sMbufB, &h->sVrowB,
                    &h->sTq, &h->sPq, &h->sNq, &h->sD5x, &h->sD5t, &h->snu5, &h->sP5x, &h->scolpart, &h->sminpart, &h->sminpart2, &h->sfroB, &h->svvB, &h->se1, &h->se2,
-                   &h->soX, &h->soW, &h->soTh, &h->sbigscr, &h->soV};
+                   &h->soX, &h->soW, &h->soTh, &h->sbigscr, &h->soV, &h->sXsB, &h->ssubSB, &h->ssubIB};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -749,6 +750,7 @@ int omc_relax_solve(omc_instance* h) {
       // global step: rows / Y (base kernel), columns (X, W, Theta, duals of the big cone), duals of the order-5 blocks, per-slot sums
       OmcWS wb = h->wbig; wb.b0 = wg.b0; wb.nB = wg.nB; wb.slot_list = wg.slot_list;
       if (w.sub_enable) MAYBE_TIMED(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
+      if (wb.sub_enable) MAYBE_TIMED(sb, OMC_KERNEL_SHOR_BIGCONE, 0, omc_launch_cone_sub(&wb, sb));
       if (h->big_lpp) MAYBE_TIMED(sb, OMC_KERNEL_SHOR_BIGCONE, gact[g], omc_launch_cone_ws(&wb, h->big_lpp, h->big_use_lds, h->big_lds, sb));
       else MAYBE_TIMED(sb, OMC_KERNEL_SHOR_BIGCONE, gact[g], omc_launch_cone(&wb, CONE_BIG, h->big_cone_lds_ok, h->big_cone_lds, sb));
       if (h->ws_lpp) MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
@@ -1015,7 +1017,7 @@ int omc_relax_batch(omc_instance* h, int B, const omc_relax_params* params, int 
 // OMC.jl:1503-1525, 1755-1779, 1838-1846; node.Shor_info lists OMC.jl:37-40.  Formulation: oracle/omc_oracle_shor.py, DESIGN.md 3.7.
 int omc_set_shor_penalties(omc_instance* h, double rho, double r4, double r5) {
   if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
-  if (!(rho > 0.0) || !(r4 > 0.0) || !(r5 > 0.0)) return fail(OMC_ERR_ARGUMENT, "penalties must be positive");
+  if (!(rho > 0.0) || !(r4 >= 0.0) || !(r5 > 0.0)) return fail(OMC_ERR_ARGUMENT, "rho and r5 must be positive, r4 non-negative (0 = automatic)");
   h->shor_rho = rho; h->shor_r4 = r4; h->shor_r5 = r5;
   return 0;
 }
@@ -1165,6 +1167,9 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
       const int* base = h->sgInts.as<int>();
       auto put = [&](const std::vector<int>& v) { const int* dp = base + o; if (!v.empty()) memcpy(&hi[o], v.data(), v.size() * sizeof(int)); o += v.size(); return dp; };
       gd[g].nq = G.nq; gd[g].nv1 = G.nv1; gd[g].nv2 = G.nv2; gd[g].pad = 0;
+      // the weight of the order-5 blocks on an entry of X / W is r4 x (blocks that hold it): r4 follows the mean multiplicity 4 nq / (n m)
+      // (measured: 20 at 12 x 14 with 152 minors, 5 at 100 x 100 with 38 813, 1.2 at 200 x 200 with 632 732 certify fastest)
+      gd[g].r4 = (h->shor_r4 > 0.0) ? h->shor_r4 : std::min(40.0, std::max(0.25, 75.0 * (double)n * (double)m / (4.0 * (double)std::max(G.nq, 1))));
       gd[g].mi = put(G.mi); gd[g].kid = put(G.kid); gd[g].cptr = put(G.cptr); gd[g].cent = put(G.cent);
       gd[g].v1ptr = put(G.v1ptr); gd[g].v1ent = put(G.v1ent); gd[g].v2ptr = put(G.v2ptr); gd[g].v2ent = put(G.v2ent); gd[g].slackrow = put(G.slackrow);
       memcpy(&hb[G.off_byte], G.eclass.data(), G.eclass.size());
@@ -1198,7 +1203,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   ENS(h->sTq, sB * 15 * nq1 * 8); ENS(h->sPq, sB * 15 * nq1 * 8); ENS(h->sNq, sB * 15 * nq1 * 8);
   ENS(h->sD5x, sB * nm * 8); ENS(h->sD5t, sB * m * 8); ENS(h->snu5, sB * m * 8); ENS(h->sP5x, sB * nm * 8);
   ENS(h->scolpart, sB * m * 4 * 8); ENS(h->sminpart, sB * nmb * 8); ENS(h->sminpart2, sB * nmb * 8);
-  ENS(h->sfroB, sB * 8); ENS(h->svvB, sB * sizeof(int)); ENS(h->se1, sB * nv11 * 8); ENS(h->se2, sB * nv21 * 8);
+  ENS(h->sfroB, sB * 2 * 8); ENS(h->svvB, sB * sizeof(int)); ENS(h->se1, sB * nv11 * 8); ENS(h->se2, sB * nv21 * 8);
   ENS(h->soX, sN * nm * 8); ENS(h->soW, sN * nm * 8); ENS(h->soTh, sN * m * m * 8);
   HIPCHK(hipMemsetAsync(h->sMbufB.p, 0, sB * NPb * NPb * 8, s));
   HIPCHK(hipMemsetAsync(h->sVrowB.p, 0, sB * NPb * NPb * 8, s));
@@ -1216,7 +1221,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   sh.Tq = h->sTq.as<double>(); sh.Pq = h->sPq.as<double>(); sh.Nq = h->sNq.as<double>();
   sh.D5x = h->sD5x.as<double>(); sh.D5t = h->sD5t.as<double>(); sh.nu5 = h->snu5.as<double>(); sh.P5x = h->sP5x.as<double>();
   sh.colpart = h->scolpart.as<double>(); sh.minpart = h->sminpart.as<double>(); sh.minpart2 = h->sminpart2.as<double>();
-  sh.fro2B = h->sfroB.as<double>(); sh.vvalidB = h->svvB.as<int>();
+  sh.fro2B = h->sfroB.as<double>(); sh.trB = h->sfroB.as<double>() + sB; sh.vvalidB = h->svvB.as<int>();
   sh.Y = w.Y; sh.Yp = w.Yp; sh.rp = w.rp; sh.rd = w.rd;
   sh.e1 = h->se1.as<double>(); sh.e2 = h->se2.as<double>();
   sh.objcol = w.objcol; sh.c0col = w.c0col; sh.lamDX = w.lamDX;
@@ -1254,6 +1259,20 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
       ENS(h->sbigscr, sB * wb.cone_scratch_stride * 8);
       wb.cone_scratch = h->sbigscr.as<double>();
     }
+  }
+  // the big cone's input has a handful of positive eigenvalues once the iterate has settled (measured: 2 - 5 of n + m): the tracked-subspace
+  // kernel of the base engine follows them; the warm-started full kernel seeds the block and is the fall-back
+  wb.trM = sh.trB;
+  if (h->big_lpp && N >= 48 && omc_cone_sub_lds(NPb) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE") && !getenv("OMC_SHOR_NO_SUBSPACE")) {
+    ENS(h->sXsB, sB * NPb * 16 * 8); ENS(h->ssubSB, sB * 16 * 8); ENS(h->ssubIB, sB * 12 * sizeof(int));
+    HIPCHK(hipMemsetAsync(h->sXsB.p, 0, sB * NPb * 16 * 8, s));
+    HIPCHK(hipMemsetAsync(h->ssubSB.p, 0, sB * 16 * 8, s));
+    HIPCHK(hipMemsetAsync(h->ssubIB.p, 0, sB * 12 * sizeof(int), s));
+    int* si = h->ssubIB.as<int>();
+    sh.sub_onB = si; sh.cone_doneB = si + sB; sh.sub_waitB = si + 2 * sB; sh.sub_nfailB = si + 3 * sB;
+    wb.sub_enable = 1; wb.Xs = h->sXsB.as<double>(); wb.sub_theta = h->ssubSB.as<double>();
+    wb.sub_on = sh.sub_onB; wb.cone_done = sh.cone_doneB; wb.sub_wait = sh.sub_waitB; wb.sub_nfail = sh.sub_nfailB; wb.sub_stat = si + 4 * sB;
+    wb.sep_done = nullptr;
   }
   HIPCHK(hipStreamSynchronize(s));
   h->shor_on = true;

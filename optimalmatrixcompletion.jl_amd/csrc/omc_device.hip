@@ -1536,7 +1536,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   if (tid < SUBP) thg[tid] = th[tid];
   if (tid == 0) {
     int c = 0;
-    for (int t = 0; t < SUBP; ++t) if (th[t] > 0.0) { sel[c] = t; wgt[c] = fmin(th[t], 1.0); ++c; }
+    for (int t = 0; t < SUBP; ++t) if (th[t] > 0.0) { sel[c] = t; wgt[c] = fmin(th[t], w.clip_hi); ++c; }
     s_nsel = c;
   }
   __syncthreads();

@@ -15,6 +15,7 @@
 // index structure of one Shor list (shared by every node that carries the same list: the reference's static mode gives all nodes one list)
 struct ShorGroupDev {
   int nq, nv1, nv2, pad;
+  double r4;            // penalty of this list's order-5 blocks relative to rho (auto: 75 n m / (4 nq), clamped to [0.25, 40])
   const int* mi;        // 4 * nq: i1, i2, j1, j2 (0-based), SoA: mi[c * nq + q]
   const int* kid;       // 4 * nq: key ids of V1[i1,(j1,j2)], V1[i2,(j1,j2)], V2[(i1,i2),j1], V2[(i1,i2),j2], SoA
   const int* cptr;      // n*m + 1: CSR coordinate (column-major e = j*n + i) -> members
@@ -41,7 +42,8 @@ struct ShWS {
   double *Tq, *Pq, *Nq;                         // S * 15 * nqmax, SoA [e][q]: over-relaxed target / dual ; projection ; projection - input
   double *D5x, *D5t, *nu5, *P5x;                // S * (n*m, m, m, n*m)
   double *colpart, *minpart, *minpart2;         // S * m * 4, S * nmb, S * nmb
-  double* fro2B; int* vvalidB;                  // S
+  double *fro2B, *trB; int* vvalidB;            // S: squared Frobenius norm and trace of the big cone's next input ; eigenvectors valid
+  int *sub_onB, *cone_doneB, *sub_waitB, *sub_nfailB;   // S each: tracked-subspace state of the big cone (k_cone_sub through the view); NULL = off
   const double *Y, *Yp; double *rp, *rd;        // base state
   double *e1, *e2;                              // S * nv1max, S * nv2max: certificate: V residual per key
   double *objcol, *c0col, *lamDX;               // base certificate inputs (S*m, S*m, S*m*n)

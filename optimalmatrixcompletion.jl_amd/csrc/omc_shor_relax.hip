@@ -124,7 +124,10 @@ __global__ void __launch_bounds__(SH_T) k_shor_setup(ShWS w, double y0) {
     w.MbufB[(size_t)b * NP * NP + e] = (i == j && i < n) ? y0 : 0.0;
     w.VrowB[(size_t)b * NP * NP + e] = 0.0;
   }
-  if (tid == 0) { w.fro2B[b] = y0 * y0 * n; w.vvalidB[b] = 0; }
+  if (tid == 0) {
+    w.fro2B[b] = y0 * y0 * n; w.trB[b] = y0 * n; w.vvalidB[b] = 0;
+    if (w.sub_onB) { w.sub_onB[b] = 0; w.cone_doneB[b] = 0; w.sub_waitB[b] = 0; w.sub_nfailB[b] = 0; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_cols(ShWS w) {
   const ShorGroupDev G = w.groups[w.node_group[nb]];
   const int n = w.n, m = w.m, N = w.N, NP = w.NPb;
   const size_t nm = (size_t)n * m;
-  const double rho = w.rho_b[b], rx = w.rx, r4 = w.r4, r5 = w.r5;
+  const double rho = w.rho_b[b], rx = w.rx, r4 = G.r4, r5 = w.r5;
   double* X = w.X + b * nm + (size_t)j * n;
   double* W = w.W + b * nm + (size_t)j * n;
   double* Th = w.Th + (size_t)b * m * m + (size_t)j * m;
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_cols(ShWS w) {
   // ---- 2. X column, W on C: per-entry targets; column sums for the coupling ------------------------------------------------------
   const double cT = 1.0 / (2.0 * w.gamma) + ((ct == 1) ? 0.5 : 0.0);
   double sum_wbar = 0.0, sum_iw = 0.0;
-  double fro2 = 0.0, rp2 = 0.0, rd2 = 0.0;
+  double fro2 = 0.0, rp2 = 0.0, rd2 = 0.0, tr1 = 0.0;
   const double inv12nu = 1.0 / (1.0 + 2.0 * nu);
   for (int i = tid; i < n; i += T) {
     const int cl = ecl[i];
@@ -358,6 +361,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_cols(ShWS w) {
     const double mv = tn - d0n;
     Mb[(size_t)cj * NP + n + jp] = mv;
     fro2 += mv * mv;
+    if (jp == j) tr1 += mv;
     rp2 += (p0 - tn) * (p0 - tn);
     rd2 += (tn - tho) * (tn - tho);
     Th[jp] = tn;
@@ -375,12 +379,14 @@ __global__ void __launch_bounds__(SH_T) k_shor_cols(ShWS w) {
       const double mv = yn - d0n;
       Mb[(size_t)j * NP + i] = mv;
       fro2 += mv * mv;
+      if (i == j) tr1 += mv;
       rp2 += (p0 - yn) * (p0 - yn);
     }
   }
   fro2 = block_sum(fro2, red);
   rp2 = block_sum(rp2, red);
   rd2 = block_sum(rd2, red);
+  tr1 = block_sum(tr1, red);
   if (tid == 0) {
     if (ct != 2) {
       const double tnew = thn - swn;
@@ -389,7 +395,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_cols(ShWS w) {
       rp2 += (p5t - tnew) * (p5t - tnew);
     }
     double* cp = w.colpart + ((size_t)b * m + j) * 4;
-    cp[0] = fro2; cp[1] = rp2; cp[2] = rd2;
+    cp[0] = fro2; cp[1] = rp2; cp[2] = rd2; cp[3] = tr1;
   }
 }
 
@@ -398,14 +404,15 @@ __global__ void __launch_bounds__(SH_T) k_shor_reduce(ShWS w) {
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
-  double f = 0.0, p = 0.0, d = 0.0;
-  for (int j = tid; j < w.m; j += T) { const double* cp = w.colpart + ((size_t)b * w.m + j) * 4; f += cp[0]; p += cp[1]; d += cp[2]; }
+  double f = 0.0, p = 0.0, d = 0.0, tr = 0.0;
+  for (int j = tid; j < w.m; j += T) { const double* cp = w.colpart + ((size_t)b * w.m + j) * 4; f += cp[0]; p += cp[1]; d += cp[2]; tr += cp[3]; }
   const int nb = w.node_of[b];
   const int nblk = (w.groups[w.node_group[nb]].nq + SH_T - 1) / SH_T;
   for (int t = tid; t < nblk; t += T) p += w.minpart[(size_t)b * w.nmb + t];
-  f = block_sum(f, red); p = block_sum(p, red); d = block_sum(d, red);
+  f = block_sum(f, red); p = block_sum(p, red); d = block_sum(d, red); tr = block_sum(tr, red);
   if (tid == 0) {
-    w.fro2B[b] = f;
+    w.fro2B[b] = f; w.trB[b] = tr;
+    if (w.cone_doneB) w.cone_doneB[b] = 0;
     const double rp0 = w.rp[b], rd0 = w.rd[b];
     w.rp[b] = sqrt(rp0 * rp0 + p);
     w.rd[b] = sqrt(rd0 * rd0 + d);
@@ -427,7 +434,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_chk_keys(ShWS w) {
   const ShorGroupDev G = w.groups[w.node_group[nb]];
   const int t = blockIdx.x * SH_T + threadIdx.x;
   const double* Nq = w.Nq + (size_t)b * 15 * w.nqmax;
-  const double sc = w.rho_b[b] * w.r4;
+  const double sc = w.rho_b[b] * G.r4;
   if (t < G.nv1) {
     double s = 0.0; const int p0 = G.v1ptr[t], p1 = G.v1ptr[t + 1];
     for (int p = p0; p < p1; ++p) { const int ent = G.v1ent[p]; s += Nq[(size_t)((ent & 1) ? 13 : 4) * w.nqmax + (ent >> 1)]; }
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_chk_minor(ShWS w) {
   if (q < G.nq) {
     const int nq = G.nq;
     double* Nq = w.Nq + (size_t)b * 15 * w.nqmax + q;
-    const double sc = w.rho_b[b] * w.r4;
+    const double sc = w.rho_b[b] * G.r4;
     const double e12 = w.e1[(size_t)b * w.nv1max + G.kid[q]], e34 = w.e1[(size_t)b * w.nv1max + G.kid[nq + q]];
     const double e13 = w.e2[(size_t)b * w.nv2max + G.kid[2 * nq + q]], e24 = w.e2[(size_t)b * w.nv2max + G.kid[3 * nq + q]];
     const double e3 = 0.5 * sc * (Nq[(size_t)11 * w.nqmax] + Nq[(size_t)8 * w.nqmax]);
@@ -580,7 +587,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_rescale(ShWS w) {
   for (size_t e = tid; e < (size_t)15 * w.nqmax; e += T) w.Tq[(size_t)b * 15 * w.nqmax + e] *= inv;
   for (size_t e = tid; e < nm; e += T) w.D5x[b * nm + e] *= inv;
   for (int e = tid; e < m; e += T) w.D5t[(size_t)b * m + e] *= inv;
-  double fr2 = 0.0;
+  double fr2 = 0.0, tr1 = 0.0;
   for (size_t e = tid; e < (size_t)N * N; e += T) {
     const int i = (int)(e % N), jj = (int)(e / N);
     const double d = w.D0[(size_t)b * N * N + e] * inv;
@@ -593,9 +600,11 @@ __global__ void __launch_bounds__(SH_T) k_shor_rescale(ShWS w) {
     const double mv = g - d;
     w.MbufB[(size_t)b * NP * NP + (size_t)jj * NP + i] = mv;
     fr2 += mv * mv;
+    if (i == jj) tr1 += mv;
   }
   fr2 = block_sum(fr2, red);
-  if (tid == 0) w.fro2B[b] = fr2;
+  tr1 = block_sum(tr1, red);
+  if (tid == 0) { w.fro2B[b] = fr2; w.trB[b] = tr1; }
 }
 
 // results of the slots flagged fin: X, Theta unscaled; the full W of the reference's program (X^2 on the SOC entries, the slack of

@@ -47,7 +47,7 @@ class ShorParams:
     max_iters: int = 6000
     check_every: int = 25
     rho: float = 0.05            # penalty of the cone blocks, in the scaled variables
-    r4: float = 20.0             # penalty of the minor blocks relative to rho
+    r4: float = 0.0              # penalty of the minor blocks relative to rho; 0 = automatic: 75 n m / (4 nq) clamped to [0.25, 40]
     r5: float = 2.0              # penalty of the column paraboloids relative to rho
     relax: float = 1.6
     time_limit: float = 3600.0
@@ -224,7 +224,8 @@ def sdp_relaxation_shor(inst, shor_idx, soc_idx, cuts=(), cut_type="linear", U_l
     cW = np.where(mask & inC, 0.5, 0.0) - np.where(inC & (ctype == 1)[None, :], 0.5, 0.0)
     cT = 1.0 / (2.0 * g) + np.where(ctype == 1, 0.5, 0.0)
     const0 = 0.5 * float((Ah[mask] ** 2).sum())
-    rho = p.rho; rx = p.relax; r4 = p.r4; r5 = p.r5
+    rho = p.rho; rx = p.relax; r5 = p.r5
+    r4 = p.r4 if p.r4 > 0 else min(40.0, max(0.25, 75.0 * n * m / (4.0 * max(nq, 1))))
     wY = 3.0                                          # big cone, clip, small cone
     wX = 2.0 + 2.0 * r4 * st.cntC + r5 * inS          # big cone (two symmetric positions), minors (two each), paraboloid copy
     wW = r4 * st.cntC

@@ -204,32 +204,37 @@ def test_error_conditions(have_gpu, omc, orc):
     eng2.close()
 
 
-def test_config3_full_size_with_the_real_class4_list_properties(have_gpu, omc, orc):
+def test_config3_full_size_with_the_real_class4_list_certified(have_gpu, omc, orc):
     """BASELINE config 3 as defined: 200 x 200 rank 1, 20 % observed, add_Shor_valid_inequalities = true with
-    Shor_valid_inequalities_noisy_rank1_num_entries_present = [4], static list (OMC.jl:646-669) -- the list comes from the device
-    enumeration (omc_shor_indexes) and feeds omc_relax_stage_shor.  The oracle would need hours at this size, so the node is
-    stopped at an iteration cap and checked through size-independent properties: the returned point satisfies Theta_jj = sum_i W_ij
-    and W >= X^2 on the SOC list exactly, OMC.jl:1960-1967 on it reproduces the reported objective, the bound is finite and below the
-    master objective of the altmin point (a valid upper bound of the relaxation), and the Shor kernels did run."""
+    Shor_valid_inequalities_noisy_rank1_num_entries_present = [4], static list (OMC.jl:646-669) -- the list (632 732 minors) comes from the
+    device enumeration (omc_shor_indexes) and feeds omc_relax_stage_shor.  The numpy oracle would need hours at this size, so the root is
+    relaxed to its certificate (two-sided gap 1e-5: the tolerance SURVEY 8c states for the Shor configurations) and checked through
+    size-independent properties: Theta_jj = sum_i W_ij and W >= X^2 on the SOC list hold exactly, OMC.jl:1960-1967 on the returned point
+    reproduces the reported objective, and the value is sandwiched between the certified bound of the base relaxation (the minors only
+    cut) and the master objective of the rank-1 altmin point (feasible for every minor)."""
     A, mask = orc.make_instance(200, 200, 1, n_indices=8000, seed=0, noise=0.01)
     eng = omc.Engine(A, mask, GAMMA, 1)
     minors = eng.generate_rank1_matrix_completion_Shor_constraints_indexes([4])
     assert len(minors) > 1e5
-    cap = 150
-    r = eng.matrix_completion_SDP_relaxation([[]], "linear", omc.default_params(max_iters=cap, check_every=25), add_Shor_valid_inequalities=True,
+    r = eng.matrix_completion_SDP_relaxation([[]], "linear", omc.default_params(max_iters=5000, eps_gap=1e-5), add_Shor_valid_inequalities=True,
                                              shor_info=[(minors, None)], want_Theta=True)[0]
-    assert r["iters"] == cap and r["status_code"] == 1
-    assert np.isfinite(r["objective"]) and np.isfinite(r["X"]).all() and np.isfinite(r["W"]).all() and np.isfinite(r["Theta"]).all()
+    assert r["status_code"] == 0, (r["iters"], r["objective"], r["dual_bound"])
+    assert abs(r["objective"] - r["dual_bound"]) <= 1.01e-5 * max(1.0, abs(r["objective"]))
+    assert np.isfinite(r["X"]).all() and np.isfinite(r["W"]).all() and np.isfinite(r["Theta"]).all()
     assert np.abs(np.diag(r["Theta"]) - r["W"].sum(0)).max() <= 1e-9 * max(1.0, np.abs(np.diag(r["Theta"])).max())
     cov = np.zeros(mask.shape, bool)
     mi = np.asarray(minors) - 1
     cov[mi[:, 0], mi[:, 2]] = True; cov[mi[:, 0], mi[:, 3]] = True; cov[mi[:, 1], mi[:, 2]] = True; cov[mi[:, 1], mi[:, 3]] = True
-    assert ((r["W"] - r["X"] ** 2)[~cov] >= -1e-9).all() and r["W"].min() >= -1e-6 * np.abs(r["W"]).max()
+    # the column sums are exact by construction; the slack row of a column carries theta_j - sum_i W_ij, which the paraboloid keeps >= 0
+    # only to the feasibility tolerance of the certificate
+    tolW = 2e-5 * max(1.0, np.abs(r["W"]).max())
+    assert ((r["W"] - r["X"] ** 2)[~cov] >= -tolW).all() and r["W"].min() >= -tolW
     assert orc.compute_SDP_relaxation_objective(r["X"], r["Theta"], A, mask, GAMMA, W=r["W"]) == pytest.approx(r["objective"], rel=1e-8)
+    big = np.block([[r["Y"], r["X"]], [r["X"].T, r["Theta"]]])
+    assert np.linalg.eigvalsh(0.5 * (big + big.T))[0] >= -1e-8 * np.linalg.norm(r["Theta"], 2)
+    rb = eng.matrix_completion_SDP_relaxation([[]], "linear", omc.default_params(rho_scale=4.0), want_X=False)[0]
     am = eng.alternating_minimization([orc.svd_rounding(np.where(mask, A, 0.0), 1)])[0]
-    assert r["dual_bound"] <= am["master_objective"] * (1 + 1e-9)
-    ks = eng.kernel_stats()          # one slot: the iteration body is replayed from a hipGraph, which is accounted to "global"
-    assert ks["global"]["launches"] >= cap and ks["colprox"]["launches"] == 0 and ks["check_col"]["launches"] == cap // 25
+    assert rb["dual_bound"] * (1 - 1e-6) <= r["objective"] <= am["master_objective"] * (1 + 1e-6)
     eng.close()
 
 
