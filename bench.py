@@ -85,7 +85,7 @@ def cpu_baseline_legs(A, mask, gamma, k, cut_type, rho_scale, nodes, depth):
     t1 = time.perf_counter()
     one = _cpu_worker((A, mask, gamma, k, cut_type, rho_scale, nodes))
     t_one = time.perf_counter() - t1
-    workers = min(nproc, 16)        # the CPU share of a one-GPU box
+    workers = max(1, min(nproc, int(os.environ.get("OMC_BENCH_CPU_WORKERS", nproc))))        # every host core (the leg used 16 of 256)
     sample = [nodes[i % len(nodes)] for i in range(workers)]
     ctx = mp.get_context("spawn")
     t1 = time.perf_counter()
@@ -233,9 +233,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
     info = eng.solver_info()
-    value = B * args.steps * world / el
+    value_all = B * args.steps * world / el
     iters = np.array([o["iters"] for o in out]); status = np.bincount([o["status_code"] for o in out], minlength=4)
     certified = int(status[0] + status[3])
+    # headline = nodes returned with a certificate (two-sided gap 1e-6, or proven infeasible) per second; SLOW_PROGRESS nodes come back
+    # with values and a valid bound (MOI.SLOW_PROGRESS, OMC.jl:1871-1877) and are counted in value_all only
+    value = value_all * certified / B
 
     # ---- roofline of the cone block (the kernel class VERDICT r01 named): batched order-n spectral projection = k_cone_sub (tracked
     # subspace, MFMA) + k_cone_ws (full eigendecomposition: seed / fall-back).  Algorithmic flops per projection F_proj(n)
@@ -248,13 +251,32 @@ def main():
     executed_sub = (sub.get("power_steps", 0) + sub.get("ritz_passes", 0)) * 2.0 * np16 * np16 * 16     # MFMA flops of the M X products of k_cone_sub
     traffic = None; peak_measured = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_cone_traffic.json")) as f:
-            traffic = json.load(f)
+        with open(os.path.join(ROOT, "profiles", "r03_cone_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_cone_traffic.json")) else "r02_cone_traffic.json")) as f:
+            traffic = json.load(f)             # PMC passes are separate rocprofv3 runs (tools/prof_round3.sh); the file says which regime it describes
         with open(os.path.join(ROOT, "profiles", "r02_fp64_peak.json")) as f:
             peak_measured = json.load(f)
     except Exception:
         pass
     per_kernel = {c: dict(ms=round(v["ms"], 2), launches=v["launches"], avg_launch_ms=round(v["ms"] / max(1, v["launches"]), 4)) for c, v in kstats.items()}
+    # one roofline per iteration kernel: algorithmic work per node-iteration x node-iterations / the kernel's HIP-event time
+    cj = mask.sum(0).astype(float)
+    f_frac = float((cj ** 3 / 3.0 + 2.0 * cj ** 2).sum())                     # K-FRAC: one factorisation + solves per observed column
+    b_frac = 8.0 * n * m + n * m / 8.0 + 16.0 * n * n                         # A, mask, Y in, gradient out
+    b_glob = 96.0 * n * n                                                     # k_global: Y, D1, D3, W1, E3, weights in; Y, Yp, D1, D3, next cone input out (12 n^2 doubles)
+    r_eff = max(1, int(info["r_max"]))
+    f_small = 4.0 * n * n * r_eff + 13.0 / 3.0 * (r_eff + k) ** 3
+    HBM_PEAK = 8.0                                                            # TB/s, MI355X_MICROARCH.md
+    def kroof(name, cls, bound, work, peak, unit):
+        ms_ = sum(kstats[c]["ms"] for c in cls)
+        ach = work * projections / max(ms_ * 1e-3, 1e-12) / 1e12
+        return dict(kernel=name, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, ms=round(ms_, 2), work_per_node_iteration=work)
+    kernel_rooflines = [
+        kroof("k_colprox", ["colprox"], "mfma", f_frac, F64_PEAK_TFLOPS, "TFLOP/s"),
+        kroof("k_colprox (bytes)", ["colprox"], "hbm", b_frac, HBM_PEAK, "TB/s"),
+        kroof("cone block: k_cone_sub + k_cone_ws", ["cone", "cone_sub"], "mfma", f_proj(n), F64_PEAK_TFLOPS, "TFLOP/s"),
+        kroof("k_global", ["global"], "hbm", b_glob, HBM_PEAK, "TB/s"),
+        kroof("k_small", ["small"], "mfma", f_small, F64_PEAK_TFLOPS, "TFLOP/s"),
+    ]
     roofline = dict(bound="mfma", kernel="cone block: k_cone_sub + k_cone_ws", achieved=achieved, peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / F64_PEAK_TFLOPS,
                     traffic=traffic, peak_measured=peak_measured, avg_launch_ms=cone_ms / launches, matrices_per_launch=projections / launches, order=n,
                     note="algorithmic flops F_proj(n) = 13/3 n^3 per projection (SURVEY 8d) over the summed HIP-event time of both cone kernels; "
@@ -263,7 +285,7 @@ def main():
                     executed_subspace_tflops=executed_sub / max(kstats["cone_sub"]["ms"] * 1e-3, 1e-12) / 1e12, subspace=sub,
                     concurrency="the cone kernels share the CUs with k_colprox and k_small of the same iteration (three HIP streams); OMC_STREAMS=1 runs "
                                 "the kernels back to back (profiles/ has both)",
-                    kernel_ms=per_kernel)
+                    kernel_ms=per_kernel, kernels=kernel_rooflines)
 
     if graph_env is None:
         os.environ.pop("OMC_GRAPH_MAX", None)
@@ -308,11 +330,46 @@ def main():
             tt.append(dict(seed=sd, seconds=time.perf_counter() - t1, gap=sol["gap"], nodes_relaxed=inst2["run_details"]["nodes_relax_feasible"]))
             e2.close()
         extras["time_to_gap"] = dict(target_gap=1e-4, runs=tt, median_seconds=float(np.median([t_["seconds"] for t_ in tt])))
+        # ---- the same on BASELINE config 1 (README quick-start: 50 x 50 pure noise, gamma = 80, bestfirst + linear cuts): a tree that branches ----
+        try:
+            A1, mask1, g1, c1 = data.config_instance(1, seed=0)
+            e1 = omc_amd.Engine(A1, mask1, g1, c1["k"], device=local)
+            t1 = time.perf_counter()
+            sol1, inst1 = bnb.branch_and_bound(e1, A1, mask1, gap=1e-4, time_limit=float(os.environ.get("OMC_BENCH_CFG1_SECONDS", 45)), batch=256, disjunctive_cuts_type=c1["cut_type"])
+            tb1 = time.perf_counter() - t1
+            rd1 = inst1["run_details"]; lg = inst1["run_log"]
+            traj = [dict(seconds=round(r_[6], 2), explored=int(r_[0]), lower=r_[3], upper=r_[4], gap=r_[5]) for r_ in lg[:: max(1, len(lg) // 8)]]
+            extras["time_to_gap_config1"] = dict(instance="config 1: README quick-start 50x50, A iid N(0,1), mask Bernoulli(1/2), seed 0", seconds=tb1, reached_gap=bool(sol1["gap"] <= 1e-4),
+                                                  gap=sol1["gap"], lower_bound=sol1["lower_bound"], upper_bound=sol1["objective"], nodes_relaxed=rd1["nodes_relax_feasible"],
+                                                  nodes_per_s=rd1["nodes_relax_feasible"] / max(rd1["solve_time_relaxation"], 1e-9), trajectory=traj)
+            e1.close()
+        except Exception as ex:
+            extras["time_to_gap_config1"] = dict(error=repr(ex))
+        # ---- BASELINE config 3 as defined: 200 x 200 rank 1 with add_Shor_valid_inequalities = true, static class-4 list (Shor mode) ------------
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            A3, mask3, g3, c3 = data.config_instance(3, seed=0)
+            e3 = omc_amd.Engine(A3, mask3, g3, 1, device=local)
+            mi3 = e3.generate_rank1_matrix_completion_Shor_constraints_indexes([4])
+            nb3 = int(os.environ.get("OMC_BENCH_SHOR_NODES", 8)); it3 = int(os.environ.get("OMC_BENCH_SHOR_ITERS", 400))
+            os.environ["OMC_GRAPH_MAX"] = "0"
+            e3.stage_shor([[]] * nb3, [(mi3, None)] * nb3, "linear", omc_amd.default_params(max_iters=it3, slots=nb3, eps_gap=1e-5))
+            t1 = time.perf_counter(); e3.solve(); ts3 = time.perf_counter() - t1
+            o3 = e3.fetch(want_Y=False, want_X=False)
+            ks3 = {c_: round(v_["ms"], 1) for c_, v_ in e3.kernel_stats().items() if v_["launches"]}
+            os.environ.pop("OMC_GRAPH_MAX", None)
+            extras["shor_config3"] = dict(workload=f"config 3: 200x200 rank-1, {len(mi3)} class-4 minors (device enumeration), {nb3} root copies, {it3} ADMM iterations each (a root certifies 1e-5 in ~2550: tests/test_gpu_shor.py)",
+                                          minors=int(len(mi3)), node_iterations_per_s=nb3 * int(o3[0]["iters"]) / ts3, ms_per_iteration=ts3 / max(1, int(o3[0]["iters"])) * 1e3,
+                                          kernel_ms=ks3, big_cone_order=int(A3.shape[0] + A3.shape[1]),
+                                          big_cone_tflops=f_proj(A3.shape[0] + A3.shape[1]) * nb3 * int(o3[0]["iters"]) / max(ks3.get("shor_bigcone", 0.0) * 1e-3, 1e-12) / 1e12)
+            e3.close()
+        except Exception as ex:
+            extras["shor_config3"] = dict(error=repr(ex))
         if args.cpu_nodes > 0:
             extras["cpu_baseline"] = cpu_baseline_legs(A, mask, gamma, k, cfg["cut_type"], rho_scale, nodes[: args.cpu_nodes], args.depth)
     if rank == 0:
         print(json.dumps({
-            "metric": "B&B node-relaxations/sec, 100x100 k=1", "value": value, "unit": "node-relaxations/s", "n_gpus": world,
+            "metric": "B&B node-relaxations/sec, 100x100 k=1", "value": value, "value_note": "nodes returned with a certificate per second; all nodes (certified + SLOW_PROGRESS with values and a valid bound): config.nodes_per_s_all", "unit": "node-relaxations/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config {args.config}: {n}x{m} rank-{k}, gamma=80, 20% observed, {cfg['cut_type']} cuts, smallest_1_eigvec; "
@@ -320,11 +377,12 @@ def main():
                                    + (", each rank its own subtrees" if world > 1 else "") + ")",
                        "nodes_per_gpu": B, "slots": min(args.slots, B), "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
                        "status_counts": {"optimal": int(status[0]), "slow_progress": int(status[1]), "time_limit": int(status[2]), "infeasible": int(status[3])},
-                       "certified_fraction": certified / B, "certified_nodes_per_s": value * certified / B,
+                       "certified_fraction": certified / B, "certified_nodes_per_s": value, "nodes_per_s_all": value_all,
                        "bounds_exchange": (comm_kind if use_comm else None),
                        "jacobi_sweeps_last_step": info["jacobi_sweeps"], "instance_sha256": data.instance_sha256(A, mask)[:16]},
             "roofline": roofline, "cpu_baseline": extras.get("cpu_baseline"), "time_to_gap": extras.get("time_to_gap"),
-            "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"),
+            "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"), "time_to_gap_config1": extras.get("time_to_gap_config1"),
+            "shor_config3": extras.get("shor_config3"),
         }))
     eng.close()
     if dist.is_initialized():

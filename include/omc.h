@@ -267,6 +267,8 @@ int omc_last_solver_info(omc_instance* h, double* info);
  * seedings of the tracked subspace by the full kernel, fall-backs by cause (more than 12 positive Ritz values, step cap, Cholesky
  * breakdown), Rayleigh-Ritz passes */
 int omc_last_subspace_stats(omc_instance* h, int64_t* out);
+/* the same eight counters for the order-(n+m) cone of the last Shor-mode solve */
+int omc_last_shor_subspace_stats(omc_instance* h, int64_t* out);
 /* diagnostic builds (-DOMC_STAMPS) only: accumulated s_memtime ticks per kernel phase of node 0; zeros otherwise */
 int omc_debug_stamps(omc_instance* h, double* out32);
 /* diagnostic builds only: per-slot counters, out[c * slots + b]: c = 0 colprox wave cycles, 1 factorizations, 2 cone cycles,

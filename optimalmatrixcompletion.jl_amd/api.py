@@ -228,6 +228,13 @@ class Engine:
         return dict(calls=int(out[0]), power_steps=int(out[1]), fallbacks=int(out[2]), seeds=int(out[3]), fail_positive=int(out[4]),
                     fail_steps=int(out[5]), fail_cholesky=int(out[6]), ritz_passes=int(out[7]))
 
+    def shor_subspace_stats(self):
+        """The same counters for the order-(n+m) cone of the last Shor-mode solve."""
+        out = np.zeros(8, np.int64)
+        _lib.check(self._lib.omc_last_shor_subspace_stats(self._h, _lib.ptr(out)))
+        return dict(calls=int(out[0]), power_steps=int(out[1]), fallbacks=int(out[2]), seeds=int(out[3]), fail_positive=int(out[4]),
+                    fail_steps=int(out[5]), fail_cholesky=int(out[6]), ritz_passes=int(out[7]))
+
     def solver_info(self):
         info = np.zeros(8)
         _lib.check(self._lib.omc_last_solver_info(self._h, _lib.ptr(info)))

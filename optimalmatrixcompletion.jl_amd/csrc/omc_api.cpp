@@ -927,6 +927,15 @@ int omc_relax_solve(omc_instance* h) {
     for (int b = 0; b < S; ++b) for (int q = 0; q < 8; ++q) h->sub_tot[q] += ss[8 * b + q];
     HIPCHK(hipMemsetAsync(w.sub_stat, 0, sizeof(int) * ss.size(), s));
   }
+  if (shor && h->wbig.sub_enable) {      // tracked-subspace accounting of the big cone (same layout as omc_last_subspace_stats)
+    std::vector<int> ss(8 * (size_t)S);
+    HIPCHK(hipMemcpyAsync(ss.data(), h->wbig.sub_stat, sizeof(int) * ss.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int q = 0; q < 8; ++q) h->big_sub_tot[q] = 0;
+    for (int b = 0; b < S; ++b) for (int q = 0; q < 8; ++q) h->big_sub_tot[q] += ss[8 * b + q];
+    if (getenv("OMC_SHOR_DEBUG")) for (int b = 0; b < S && b < 4; ++b) fprintf(stderr, "slot %d big-cone subspace: calls %d steps %d fallbacks %d seeds %d\n", b, ss[8 * b], ss[8 * b + 1], ss[8 * b + 2], ss[8 * b + 3]);
+    HIPCHK(hipMemsetAsync(h->wbig.sub_stat, 0, sizeof(int) * ss.size(), s));
+  }
   HIPCHK(hipGetLastError());
   finish_events(h);
   h->last_solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1293,6 +1302,12 @@ int omc_relax_fetch_shor_V(omc_instance* h, double* V) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpyAsync(V, h->sh.oV, 8 * (size_t)h->sh.Btot * 5 * (size_t)std::max(h->sh.nqmax, 1), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int omc_last_shor_subspace_stats(omc_instance* h, int64_t* out) {
+  if (!h || !out) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  for (int q = 0; q < 8; ++q) out[q] = h->big_sub_tot[q];
   return 0;
 }
 

@@ -1529,6 +1529,8 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
       atomicAdd(&w.sub_stat[8 * b + 2], 1); atomicAdd(&w.sub_stat[8 * b + 3 + fail], 1);   // 4: too many positive Ritz values, 5: step cap, 6: Cholesky
       const int nf = w.sub_nfail[b] + 1;          // exponential back-off: the spectrum still moves too fast for the tracked block
       w.sub_nfail[b] = nf; w.sub_wait[b] = (nf >= 7) ? 128 : (1 << nf);
+    } else if (w.sub_nfail[b] > 0 && (w.iters[b] & 15) == 0) {
+      w.sub_nfail[b] -= 1;                        // ... and forgets: a failure every few hundred calls (long solves: Shor mode runs thousands of iterations) must not cost 128 full decompositions each
     }
   }
   if (!ok) return;                       // cone_done stays 0: the full kernel projects this slot (and re-seeds X)

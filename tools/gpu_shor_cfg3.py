@@ -21,4 +21,4 @@ ks = {k_: (round(v["ms"], 1), v["launches"]) for k_, v in eng.kernel_stats().ite
 print(json.dumps(dict(minors=int(len(minors)), B=B, iters=int(out[0]["iters"]), enum_s=round(t_enum, 3), stage_s=round(t_stage, 3), solve_s=round(t_solve, 3),
                       ms_per_iteration=round(t_solve / max(1, out[0]["iters"]) * 1e3, 3), node_iterations_per_s=round(B * out[0]["iters"] / t_solve, 1),
                       objective=out[0]["objective"], dual_bound=out[0]["dual_bound"], status=out[0]["status_code"], kernels_ms_launches=ks,
-                      no_subspace=bool(os.environ.get("OMC_SHOR_NO_SUBSPACE")))))
+                      no_subspace=bool(os.environ.get("OMC_SHOR_NO_SUBSPACE")), big_sub=eng.shor_subspace_stats(), sub=eng.subspace_stats())))
