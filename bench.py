@@ -133,8 +133,10 @@ def main():
     import torch
     import torch.distributed as dist
     if world > 1:
+        # torch.distributed only carries the rendezvous (the 128-byte RCCL id), the barriers and the MAX of the step times: a gloo group on
+        # the host, so that the ONE RCCL instance of the process is the library's own communicator (C ABI), which carries the data path
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import omc_amd
     bnb, data = omc_amd.pkg.bnb, omc_amd.pkg.data
 
@@ -147,21 +149,21 @@ def main():
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=0, world_size=1)
+            dist.init_process_group("gloo", rank=0, world_size=1)
         box = [eng.comm_unique_id().tobytes() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm_kind = "omc_allreduce_bounds (library RCCL communicator)"
         try:
             eng.comm_init(rank, world, np.frombuffer(box[0], dtype=np.uint8))
             ok = 1
-        except Exception as e:          # e.g. a second RCCL instance refused by the runtime: the bounds then travel over torch.distributed (RCCL too)
-            print(f"bench.py rank {rank}: omc_comm_init failed ({e}); falling back to torch.distributed all_reduce", file=sys.stderr)
+        except Exception as e:          # RCCL not loadable / init refused: the 16 bytes then travel over the gloo group (reported in config.bounds_exchange)
+            print(f"bench.py rank {rank}: omc_comm_init failed ({e}); falling back to torch.distributed (gloo) all_reduce", file=sys.stderr)
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
         lib_comm = bool(int(flag[0]))
         if not lib_comm:
-            comm_kind = "torch.distributed all_reduce (RCCL); omc_comm_init failed"
+            comm_kind = "torch.distributed all_reduce (gloo, host); omc_comm_init failed"
     cache = args.frontier_file if world == 1 else None
     if cache and os.path.exists(cache):
         import pickle
@@ -200,7 +202,7 @@ def main():
         if use_comm and lib_comm:
             ub, lb, _ = eng.allreduce_bounds(ub, lb)
         elif use_comm:
-            t = torch.tensor([ub, lb], dtype=torch.float64, device="cuda")
+            t = torch.tensor([ub, lb], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ub, lb = float(t[0]), float(t[1])
         return (ub, lb), out
@@ -229,7 +231,7 @@ def main():
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
     info = eng.solver_info()

@@ -237,12 +237,17 @@ int omc_shor_last_stats(omc_instance* h, double* ms, int64_t* candidates);
  *   omc_comm_unique_id   : rank 0 creates the 128-byte id; the host language distributes it to the other ranks (any channel).
  *   omc_comm_init        : collective over all ranks, after every rank has created its instance on its device.
  *   omc_allreduce_bounds : in place; *owner (may be NULL) = smallest rank whose local ub equals the global minimum.
- *   omc_bcast_incumbent  : X (n*m, column-major) from rank `root` to every rank.                                                */
+ *   omc_bcast_incumbent  : X (n*m, column-major) from rank `root` to every rank.
+ *   omc_allgather_records: the small per-node records (status, objective, bound, eigenvalues, breakpoint vector, U) of every rank.       */
 #define OMC_COMM_ID_BYTES 128
 int omc_comm_unique_id(void* id_out);
 int omc_comm_init(omc_instance* h, int rank, int world_size, const void* id);
 int omc_allreduce_bounds(omc_instance* h, double* ub, double* lb, int* owner);
 int omc_bcast_incumbent(omc_instance* h, int root, double* X);
+/* all-gather of the per-node records a host driver needs on every rank to grow the same tree (OMC.jl:700-719 sees every relaxed node): `cnt` rows of
+ * `width` doubles from this rank (counts may differ between ranks); out = rows of rank 0, rank 1, ... ; counts[r] = rows of rank r.  With this the
+ * Julia host needs no second transport (MPI) beside the library's communicator. */
+int omc_allgather_records(omc_instance* h, const double* rows, int cnt, int width, double* out, int out_capacity_rows, int* counts);
 int omc_comm_destroy(omc_instance* h);
 
 /* per-kernel accounting of the last omc_relax_solve: launches and HIP-event milliseconds per kernel class */

@@ -18,7 +18,7 @@ EXPORTS = [
     "omc_last_kernel_stats", "omc_last_solver_info", "omc_last_subspace_stats", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
     "omc_shor_count", "omc_shor_indexes", "omc_violated_shor_minors", "omc_shor_last_stats",
     "omc_relax_stage_shor", "omc_relax_fetch_shor", "omc_relax_batch_shor", "omc_set_shor_penalties", "omc_set_shor_keep_V", "omc_relax_fetch_shor_V", "omc_last_shor_subspace_stats",
-    "omc_altmin_master_objectives", "omc_comm_unique_id", "omc_comm_init", "omc_allreduce_bounds", "omc_bcast_incumbent", "omc_comm_destroy",
+    "omc_altmin_master_objectives", "omc_comm_unique_id", "omc_comm_init", "omc_allreduce_bounds", "omc_bcast_incumbent", "omc_allgather_records", "omc_comm_destroy",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     lib.omc_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.omc_allreduce_bounds.argtypes = [vp, vp, vp, vp]
     lib.omc_bcast_incumbent.argtypes = [vp, C.c_int, vp]
+    lib.omc_allgather_records.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.omc_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib

@@ -260,6 +260,13 @@ class Engine:
         _lib.check(self._lib.omc_allreduce_bounds(self._h, _lib.ptr(ub), _lib.ptr(lb), _lib.ptr(ow)))
         return float(ub[0]), float(lb[0]), int(ow[0])
 
+    def allgather_records(self, rows, width, capacity_rows):
+        """Rows (cnt, width) of every rank, in rank order, through the library's communicator (omc_allgather_records)."""
+        rows = np.ascontiguousarray(np.asarray(rows, dtype=np.float64).reshape(-1, width))
+        out = np.zeros((int(capacity_rows), width)); counts = np.zeros(self.world_size, np.int32)
+        _lib.check(self._lib.omc_allgather_records(self._h, _lib.ptr(rows) if len(rows) else None, len(rows), int(width), _lib.ptr(out), int(capacity_rows), _lib.ptr(counts)))
+        return out[: int(counts.sum())]
+
     def bcast_incumbent(self, root, X):
         Xf = np.asfortranarray(np.asarray(X, np.float64).reshape(self.n, self.m))
         _lib.check(self._lib.omc_bcast_incumbent(self._h, int(root), _lib.ptr(Xf)))

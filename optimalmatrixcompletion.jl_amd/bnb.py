@@ -94,6 +94,7 @@ class Comm:
 
     def __init__(self, rank=0, world_size=1, engine=None, group=None):
         self.rank, self.world, self.group = int(rank), int(world_size), group
+        self.max_rows = 4096                 # rows per rank and round the record exchange is sized for (the driver pops at most `batch` nodes)
         self.engine = engine if (engine is not None and getattr(engine, "world_size", 1) == self.world and self.world > 1) else None
         if self.world > 1:
             import torch.distributed as dist
@@ -106,6 +107,8 @@ class Comm:
         rows = np.asarray(rows, dtype=np.float64).reshape(-1, width)
         if self.world == 1:
             return rows
+        if self.engine is not None:          # the library's own RCCL communicator: no second transport beside it (omc_allgather_records)
+            return self.engine.allgather_records(rows, width, self.max_rows * self.world)
         import torch
         import torch.distributed as dist
         cnt = torch.tensor([rows.shape[0]], dtype=torch.int64, device=self.dev)

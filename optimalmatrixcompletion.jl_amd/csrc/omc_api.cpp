@@ -1757,6 +1757,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -1772,9 +1773,10 @@ int rccl_load() {
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
   r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
   r.Broadcast = (decltype(r.Broadcast))dlsym(lib, "ncclBroadcast");
+  r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
-  if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.Broadcast || !r.CommDestroy) return fail(OMC_ERR_COMM, "librccl lacks an expected symbol");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.Broadcast || !r.AllGather || !r.CommDestroy) return fail(OMC_ERR_COMM, "librccl lacks an expected symbol");
   g_rccl = r;
   return 0;
 }
@@ -1846,6 +1848,45 @@ int omc_bcast_incumbent(omc_instance* h, int root, double* X) {
   ncclResult_t e = g_rccl.Broadcast(d, d, cnt, ncclDouble, root, (ncclComm_t)h->comm, h->stream);
   if (e != ncclSuccess) return rccl_fail(e, "ncclBroadcast(X)");
   if (h->comm_rank != root) HIPCHK(hipMemcpyAsync(X, d, 8 * cnt, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// The per-node records every rank needs to grow the same tree (the serial loop OMC.jl:700-719 sees every relaxed node: status, objective,
+// bound, eigenvalues, breakpoint vector, U -- 8 (6 + n + n k) bytes per node, never X or Y): all-gather of `cnt` rows of `width` doubles per rank.
+// Ranks may hold different counts: the counts are gathered first (8 bytes per rank), the rows are padded to the largest count, and
+// `out` receives the rows of rank 0, then rank 1, ... (sum of counts x width doubles; capacity = world x max_cnt_capacity rows).
+int omc_allgather_records(omc_instance* h, const double* rows, int cnt, int width, double* out, int out_capacity_rows, int* counts /* world */) {
+  if (!h || !out || !counts || (cnt > 0 && !rows)) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (cnt < 0 || width <= 0) return fail(OMC_ERR_ARGUMENT, "cnt / width out of range");
+  if (!h->comm) return fail(OMC_ERR_COMM, "omc_comm_init has not been called on this handle");
+  HIPCHK(hipSetDevice(h->device));
+  const int W = h->comm_world;
+  int rc = h->bcomm.ensure(64 + 8 * (size_t)W); if (rc) return rc;
+  double* d = h->bcomm.as<double>();
+  const double mine = (double)cnt;
+  HIPCHK(hipMemcpyAsync(d + 4, &mine, 8, hipMemcpyHostToDevice, h->stream));
+  ncclResult_t e = g_rccl.AllGather(d + 4, d + 8, 1, ncclDouble, (ncclComm_t)h->comm, h->stream);
+  if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather(counts)");
+  std::vector<double> hc(W);
+  HIPCHK(hipMemcpyAsync(hc.data(), d + 8, 8 * (size_t)W, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int cmax = 0; long tot = 0;
+  for (int r = 0; r < W; ++r) { counts[r] = (int)hc[r]; cmax = std::max(cmax, counts[r]); tot += counts[r]; }
+  if (tot > out_capacity_rows) return fail(OMC_ERR_ARGUMENT, "omc_allgather_records: out is too small for the gathered rows");
+  if (cmax == 0) return 0;
+  const size_t blk = (size_t)cmax * width;
+  if ((rc = h->bXin.ensure(8 * blk * (size_t)(W + 1) + 64))) return rc;
+  double* send = h->bXin.as<double>(); double* recv = send + blk;
+  HIPCHK(hipMemsetAsync(send, 0, 8 * blk, h->stream));
+  if (cnt) HIPCHK(hipMemcpyAsync(send, rows, 8 * (size_t)cnt * width, hipMemcpyHostToDevice, h->stream));
+  e = g_rccl.AllGather(send, recv, blk, ncclDouble, (ncclComm_t)h->comm, h->stream);
+  if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather(records)");
+  size_t o = 0;
+  for (int r = 0; r < W; ++r) {
+    if (counts[r]) HIPCHK(hipMemcpyAsync(out + o, recv + (size_t)r * blk, 8 * (size_t)counts[r] * width, hipMemcpyDeviceToHost, h->stream));
+    o += (size_t)counts[r] * width;
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }

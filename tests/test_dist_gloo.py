@@ -117,3 +117,81 @@ def test_branch_and_bound_two_ranks_matches_single_rank():
         assert r[4] == single[4] and r[5] == single[5] and r[7] == single[7]
         assert [t[:6] for t in r[8]] == [t[:6] for t in single[8]]     # explored / total / remaining / lower / upper / gap per round
     assert two[0][6] + two[1][6] == single[6] and min(two[0][6], two[1][6]) > 0      # the relaxations were shared, none was repeated
+
+
+# ---- Comm through an engine-side communicator (the C-ABI path: omc_allreduce_bounds / omc_bcast_incumbent / omc_allgather_records) ------
+class StubCommEngine:
+    """Stands in for the library's RCCL communicator with the same three calls and the same semantics (owner = smallest rank that holds the
+    minimal upper bound; broadcast from any root; rows of every rank in rank order), carried by gloo so that it runs without a GPU."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world_size = rank, world
+        self.calls = dict(allreduce=0, bcast=0, allgather=0)
+
+    def allreduce_bounds(self, ub, lb):
+        import torch, torch.distributed as dist
+        self.calls["allreduce"] += 1
+        t = torch.tensor([float(ub), float(lb)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        o = torch.tensor([float(self.rank) if float(ub) == float(t[0]) else float(self.world_size)], dtype=torch.float64)
+        dist.all_reduce(o, op=dist.ReduceOp.MIN)
+        return float(t[0]), float(t[1]), int(o[0])
+
+    def bcast_incumbent(self, root, X):
+        import numpy as np, torch, torch.distributed as dist
+        self.calls["bcast"] += 1
+        t = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64).copy())
+        dist.broadcast(t, src=root)
+        return t.numpy()
+
+    def allgather_records(self, rows, width, capacity_rows):
+        import numpy as np, torch.distributed as dist
+        self.calls["allgather"] += 1
+        box = [None] * self.world_size
+        dist.all_gather_object(box, np.asarray(rows, dtype=np.float64).reshape(-1, width))
+        out = np.concatenate(box, axis=0)
+        assert len(out) <= capacity_rows
+        return out
+
+
+def _comm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import numpy as np
+    import torch.distributed as dist
+    import omc_amd
+    bnb = omc_amd.pkg.bnb
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = StubCommEngine(rank, world)
+    comm = bnb.Comm(rank, world, eng)
+    assert comm.engine is eng                                     # the engine-side communicator is the one used
+    # ragged record exchange: rank r contributes r + 1 rows
+    rows = np.full((rank + 1, 5), float(rank)) + np.arange(5)[None, :]
+    allrows = comm.allgather_rows(rows, 5)
+    # incumbent found by the LAST rank (a non-zero owner), broadcast from it
+    ub = 10.0 - rank; g_ub, g_lb, owner = comm.min_bounds(ub, float(rank))
+    X = np.full((3, 4), float(rank))
+    Xg = comm.bcast_matrix(X if rank == owner else np.zeros((3, 4)), owner)
+    # a tie: every rank holds the same value -> the smallest rank owns it
+    _, _, owner_tie = comm.min_bounds(7.0, 0.0)
+    dist.barrier(); dist.destroy_process_group()
+    q.put((rank, allrows.tolist(), g_ub, g_lb, owner, Xg.tolist(), owner_tie, eng.calls))
+
+
+def test_comm_through_engine_communicator_nonzero_owner_and_ragged_records():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    expect_rows = [[float(r) + c for c in range(5)] for r in range(world) for _ in range(r + 1)]
+    for rank, allrows, g_ub, g_lb, owner, Xg, owner_tie, calls in res:
+        assert allrows == expect_rows                              # rows of rank 0, then rank 1, ... on every rank
+        assert g_ub == 10.0 - (world - 1) and g_lb == 0.0 and owner == world - 1
+        assert Xg == [[float(world - 1)] * 4] * 3                  # the owner's X arrived everywhere
+        assert owner_tie == 0
+        assert calls == dict(allreduce=2, bcast=1, allgather=1)

@@ -752,6 +752,14 @@ def test_rccl_communicator_single_rank(have_gpu, omc):
     assert (ub, lb, owner) == (3.5, -1.25, 0)
     X = np.arange(A.size, dtype=float).reshape(A.shape)
     assert np.array_equal(eng.bcast_incumbent(0, X), X)
+    rows = np.arange(21, dtype=float).reshape(3, 7)                        # omc_allgather_records: the per-node records of every rank
+    assert np.array_equal(eng.allgather_records(rows, 7, 16), rows)
+    assert eng.allgather_records(np.zeros((0, 7)), 7, 16).shape == (0, 7)
+    with pytest.raises(omc.OmcError):
+        eng.allgather_records(rows, 7, 2)                                 # out too small for the gathered rows
+    # the driver counterpart takes every exchange through the engine's communicator once it exists
+    comm = omc.pkg.bnb.Comm(0, 1, eng)
+    assert np.array_equal(comm.allgather_rows(rows, 7), rows)
     with pytest.raises(omc.OmcError):
         eng.comm_init(0, 1, omc.Engine.comm_unique_id())                  # already initialised
     eng.close()
