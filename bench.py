@@ -13,6 +13,7 @@ the ranks exchange min{incumbent UB, open LB} with the library's RCCL all-reduce
 of node-parallel B&B; there is no data-path collective.
 """
 import argparse
+import faulthandler
 import json
 import os
 import subprocess
@@ -21,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+faulthandler.enable()          # a crash in native code leaves a Python traceback on stderr
 
 F64_PEAK_TFLOPS = 78.6   # AMD MI355X datasheet (vector = matrix fp64); the local guide lists no fp64 peak; measured value: profiles/r02_fp64_peak.json
 
@@ -42,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-nodes", type=int, default=4, help="nodes relaxed by the CPU oracle per leg of cpu_baseline (rank 0, N=1 only)")
     ap.add_argument("--frontier-file", default=None, help="N=1: cache of the tuned penalty scale and the frontier (written when absent, read when present) so that a "
                     "profiled run launches the kernels of the timed steps only (tools/prof_round2.sh)")
+    ap.add_argument("--warm", type=int, default=int(os.environ.get("OMC_BENCH_WARM", 1)), help="1: every node starts from its parent's final state (omc_relax_set_warm), as in a B&B run where "
+                    "a child is relaxed after its parent; 0: cold starts (the reference rebuilds every model, OMC.jl:1482)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip latency_b1 / branching / time_to_gap / cpu_baseline (rank 0, N=1 only)")
     return ap.parse_args()
 
@@ -193,7 +197,20 @@ def main():
                 nxt.extend(bnb.make_children(cuts, o, cfg["cut_type"], k) if o["feasible"] else [cuts])
             mine = nxt
         nodes = mine[:B]
-    eng.stage(nodes, cfg["cut_type"], P)           # node descriptors resident in HBM before the timed region
+    # warm start: a node of the frontier is a child of a depth-(d-1) node.  The parents are relaxed once (untimed) and leave their final states
+    # in the device pool -- inputs of the timed region, as the parent's state is an input of a child's relaxation in a B&B run
+    load_from = None; n_parents = 0
+    if args.warm:
+        pkey = {}; parents = []; load_from = []
+        for cuts in nodes:
+            key = tuple(id(c) for c in cuts[:-1]) if len(cuts) else None
+            if key not in pkey:
+                pkey[key] = len(parents); parents.append(list(cuts[:-1]))
+            load_from.append(pkey[key])
+        n_parents = len(parents)
+        eng.state_pool_create(n_parents)
+        eng.matrix_completion_SDP_relaxation(parents, cfg["cut_type"], params=P, want_Y=False, want_X=False, save_to=list(range(n_parents)))
+    eng.stage(nodes, cfg["cut_type"], P, load_from=load_from)           # node descriptors (and parent states) resident in HBM before the timed region
 
     def step():
         eng.solve()
@@ -367,6 +384,17 @@ def main():
             e3.close()
         except Exception as ex:
             extras["shor_config3"] = dict(error=repr(ex))
+        # ---- the same frontier from cold starts (what every round before round 3 measured) -------------------------------------------------
+        if args.warm:
+            try:
+                eng.stage(nodes, cfg["cut_type"], P)
+                t1 = time.perf_counter(); eng.solve(); tc = time.perf_counter() - t1
+                oc = eng.fetch(want_Y=False, want_X=False)
+                stc = np.bincount([o_["status_code"] for o_ in oc], minlength=4)
+                extras["cold_start"] = dict(nodes_per_s_all=B / tc, certified_nodes_per_s=float(stc[0] + stc[3]) / tc, certified_fraction=float(stc[0] + stc[3]) / B,
+                                            iters_median=int(np.median([o_["iters"] for o_ in oc])), seconds=tc)
+            except Exception as ex:
+                extras["cold_start"] = dict(error=repr(ex))
         if args.cpu_nodes > 0:
             extras["cpu_baseline"] = cpu_baseline_legs(A, mask, gamma, k, cfg["cut_type"], rho_scale, nodes[: args.cpu_nodes], args.depth)
     if rank == 0:
@@ -375,16 +403,17 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config {args.config}: {n}x{m} rank-{k}, gamma=80, 20% observed, {cfg['cut_type']} cuts, smallest_1_eigvec; "
-                                   f"{B} depth-{args.depth} frontier nodes per GPU per step streamed through {min(args.slots, B)} slots (continuous batching"
+                                   f"{B} depth-{args.depth} frontier nodes per GPU per step streamed through {min(args.slots, B)} slots (continuous batching, "
+                                   + ("every node warm-started from its parent's final state" if args.warm else "cold starts")
                                    + (", each rank its own subtrees" if world > 1 else "") + ")",
-                       "nodes_per_gpu": B, "slots": min(args.slots, B), "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
+                       "nodes_per_gpu": B, "slots": min(args.slots, B), "warm_start": bool(args.warm), "parent_states_in_pool": n_parents, "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
                        "status_counts": {"optimal": int(status[0]), "slow_progress": int(status[1]), "time_limit": int(status[2]), "infeasible": int(status[3])},
                        "certified_fraction": certified / B, "certified_nodes_per_s": value, "nodes_per_s_all": value_all,
                        "bounds_exchange": (comm_kind if use_comm else None),
                        "jacobi_sweeps_last_step": info["jacobi_sweeps"], "instance_sha256": data.instance_sha256(A, mask)[:16]},
             "roofline": roofline, "cpu_baseline": extras.get("cpu_baseline"), "time_to_gap": extras.get("time_to_gap"),
             "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"), "time_to_gap_config1": extras.get("time_to_gap_config1"),
-            "shor_config3": extras.get("shor_config3"),
+            "shor_config3": extras.get("shor_config3"), "cold_start": extras.get("cold_start"),
         }))
     eng.close()
     if dist.is_initialized():

@@ -140,6 +140,15 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
  * Lets one batch try several penalties on the root (autotune) or give children their parent's value. */
 int omc_set_node_rho_scales(omc_instance* h, int B, const double* rho_scale);
 int omc_relax_solve(omc_instance* h);
+/* ---- warm start from the parent's state (an addition of the engine; the reference cold-starts every model, OMC.jl:1482) ----------------------
+ * A child is its parent plus one cut.  omc_state_pool_create reserves `capacity` final states on the device (about 24 n^2 + 8 (n k + |Omega| + m
+ * + 16 n) bytes each: 0.27 MB at 100 x 100).  omc_relax_set_warm applies to the NEXT omc_relax_stage / omc_relax_batch with the same B and is
+ * consumed by it: node b starts from pool entry load_from[b] (-1 or NULL: cold start) and its final state is stored in entry save_to[b]
+ * (-1 or NULL: not stored).  The caller owns the numbering (e.g. a ring).  A warm node keeps its own base penalty (the parent's scaled
+ * duals are rescaled), inherits Y, the duals of the two full cones, the column multipliers and the tracked block of the cone; the result is the
+ * same convex program's optimum (same certificate), reached in fewer iterations.  Not available in Shor mode. */
+int omc_state_pool_create(omc_instance* h, int capacity);
+int omc_relax_set_warm(omc_instance* h, int B, const int* load_from, const int* save_to);
 /* Asynchronous form of omc_relax_solve: submit returns at once (the solve runs on a worker thread of the library), poll reports
  * progress (running flag, nodes harvested so far, nodes staged), wait joins and returns the solve's return code (message via
  * omc_last_error on the waiting thread).  The reference's loop is serial (OMC.jl:700-719); with this the host can prepare the next

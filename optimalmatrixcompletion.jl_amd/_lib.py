@@ -17,7 +17,7 @@ EXPORTS = [
     "omc_relax_fetch", "omc_relax_submit", "omc_relax_poll", "omc_relax_wait", "omc_altmin_batch", "omc_evaluate_objective", "omc_separation_batch", "omc_round_Y_batch",
     "omc_last_kernel_stats", "omc_last_solver_info", "omc_last_subspace_stats", "omc_set_node_rho_scales", "omc_debug_stamps", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
     "omc_shor_count", "omc_shor_indexes", "omc_violated_shor_minors", "omc_shor_last_stats",
-    "omc_relax_stage_shor", "omc_relax_fetch_shor", "omc_relax_batch_shor", "omc_set_shor_penalties", "omc_set_shor_keep_V", "omc_relax_fetch_shor_V", "omc_last_shor_subspace_stats",
+    "omc_relax_stage_shor", "omc_relax_fetch_shor", "omc_relax_batch_shor", "omc_set_shor_penalties", "omc_set_shor_keep_V", "omc_relax_fetch_shor_V", "omc_last_shor_subspace_stats", "omc_state_pool_create", "omc_relax_set_warm",
     "omc_altmin_master_objectives", "omc_comm_unique_id", "omc_comm_init", "omc_allreduce_bounds", "omc_bcast_incumbent", "omc_allgather_records", "omc_comm_destroy",
 ]
 
@@ -67,6 +67,8 @@ def load():
     lib.omc_set_shor_keep_V.argtypes = [vp, C.c_int]
     lib.omc_relax_fetch_shor_V.argtypes = [vp, vp]
     lib.omc_last_shor_subspace_stats.argtypes = [vp, vp]
+    lib.omc_state_pool_create.argtypes = [vp, C.c_int]
+    lib.omc_relax_set_warm.argtypes = [vp, C.c_int, vp, vp]
     lib.omc_relax_submit.argtypes = [vp]
     lib.omc_relax_poll.argtypes = [vp, vp, vp, vp]
     lib.omc_relax_wait.argtypes = [vp]

@@ -87,8 +87,19 @@ class Engine:
             pass
 
     # ---- relaxation ------------------------------------------------------------------------------------
-    def stage(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None, rho_scales=None):
+    def state_pool_create(self, capacity):
+        """Reserve `capacity` final states on the device for warm starts (omc_state_pool_create)."""
+        _lib.check(self._lib.omc_state_pool_create(self._h, int(capacity)))
+        self.pool_capacity = int(capacity)
+
+    def stage(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None, rho_scales=None, load_from=None, save_to=None):
         n, k = self.n, self.k
+        if load_from is not None or save_to is not None:
+            lf = None if load_from is None else np.ascontiguousarray(np.asarray(load_from, dtype=np.int32))
+            sv = None if save_to is None else np.ascontiguousarray(np.asarray(save_to, dtype=np.int32))
+            if (lf is not None and lf.shape != (len(nodes),)) or (sv is not None and sv.shape != (len(nodes),)):
+                raise ValueError("load_from / save_to must hold one pool index per node")
+            _lib.check(self._lib.omc_relax_set_warm(self._h, len(nodes), _lib.ptr(lf), _lib.ptr(sv)))
         if rho_scales is not None:
             rs = np.ascontiguousarray(np.asarray(rho_scales, dtype=np.float64))
             if rs.shape != (len(nodes),):
@@ -196,7 +207,7 @@ class Engine:
 
     def matrix_completion_SDP_relaxation(self, nodes, disjunctive_cuts_type="linear", params=None, U_lower=None, U_upper=None,
                                          want_Y=True, want_X=True, want_Theta=False, rho_scales=None, add_Shor_valid_inequalities=False,
-                                         shor_info=None, shor_penalties=None, want_V=False):
+                                         shor_info=None, shor_penalties=None, want_V=False, load_from=None, save_to=None):
         """Batch form of OMC.jl:1431-1943 (use_disjunctive_cuts = true).  `nodes` = list of cut lists; with
         add_Shor_valid_inequalities = True, `shor_info` = one (constraints_indexes, SOC_constraints_indexes) pair per node and
         every result also carries "W" (OMC.jl:1907-1908)."""
@@ -212,7 +223,7 @@ class Engine:
                 for r, Vb, (mi, _) in zip(out, self.fetch_shor_V(), shor_info):
                     r["V"] = Vb[:len(np.asarray(mi).reshape(-1, 4))]
             return out
-        self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper, rho_scales)
+        self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper, rho_scales, load_from, save_to)
         self.solve()
         return self.fetch(want_Y, want_X, want_Theta)
 

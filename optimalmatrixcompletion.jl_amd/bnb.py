@@ -182,7 +182,8 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                      add_Shor_valid_inequalities=False, Shor_valid_inequalities_noisy_rank1_num_entries_present=(1, 2, 3, 4),
                      add_Shor_valid_inequalities_fraction=1.0, add_Shor_valid_inequalities_iterative=False,
                      max_update_Shor_indices_probability=1.0, min_update_Shor_indices_probability=0.1,
-                     update_Shor_indices_probability_decay_rate=1.1, update_Shor_indices_n_minors=100, shor_params=None):
+                     update_Shor_indices_probability_decay_rate=1.1, update_Shor_indices_n_minors=100, shor_params=None,
+                     warm_start=True, warm_pool_bytes=6 << 30):
     """Behavioural counterpart of the reference driver for use_disjunctive_cuts = true, no Shor, one altmin run at the
     root (altmin_root_n_iters = 1).  Differences, all deliberate: (1) up to `batch` nodes are popped per round in the
     reference's selection order and relaxed in ONE GPU batch (batch=1 reproduces the serial order); (2) the node bound
@@ -282,6 +283,16 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                 root_minors = root_minors[rng.random(len(root_minors)) < add_Shor_valid_inequalities_fraction]
         shor_decay_depth = (math.log(max_update_Shor_indices_probability / min_update_Shor_indices_probability, update_Shor_indices_probability_decay_rate)
                             if add_Shor_valid_inequalities_iterative else 0.0)
+    # ---- warm-start pool: ring of final states on the device, entry -> id of the node that owns it --------------------------------
+    pool_cap = 0; pool_next = 0; pool_owner = {}
+    if warm_start and not shor and hasattr(engine, "state_pool_create"):
+        nnz = int(np.count_nonzero(indices)); np16 = (n + 15) // 16 * 16
+        state_bytes = 8 * (3 * n * n + n * k + nnz + m + 16 * np16 + 20)
+        pool_cap = int(max(0, min(1 << 17, warm_pool_bytes // state_bytes)))
+        if pool_cap >= 2:
+            engine.state_pool_create(pool_cap)
+        else:
+            pool_cap = 0
     # ---- tree ------------------------------------------------------------------------------------------------
     nodes = {1: dict(cuts=[], LB=-math.inf, depth=0, parent=0)}
     if shor:
@@ -350,6 +361,21 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                 fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=PS, want_X=True,
                                                                 add_Shor_valid_inequalities=True,
                                                                 shor_info=[(nd["shor"], None) for _, nd in need]) if need else []
+            elif pool_cap and need:
+                lf = []; sv = []
+                for nid, nd in need:
+                    ps = nd.get("pstate")          # (rank, pool entry, parent id): valid while the ring has not re-used the entry
+                    lf.append(ps[1] if (ps is not None and ps[0] == rank and pool_owner.get(ps[1]) == ps[2]) else -1)
+                busy = set(v for v in lf if v >= 0)          # entries this batch still reads: a slot may be set up after another one has been harvested
+                for nid, nd in need:
+                    while pool_next in busy and len(busy) < pool_cap:
+                        pool_next = (pool_next + 1) % pool_cap
+                    sv.append(pool_next); pool_owner[pool_next] = nid; pool_next = (pool_next + 1) % pool_cap
+                counters["warm_started"] = counters.get("warm_started", 0) + sum(1 for v in lf if v >= 0)
+                fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=P, want_X=True,
+                                                                load_from=lf, save_to=sv)
+                for (nid, nd), s_ in zip(need, sv):
+                    nd["state"] = (rank, s_, nid)
             else:
                 fresh = engine.matrix_completion_SDP_relaxation([nd["cuts"] for _, nd in need], disjunctive_cuts_type, params=P,
                                                                 want_X=True) if need else []
@@ -440,6 +466,8 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                     nodes[cid] = dict(cuts=cuts, LB=nd["LB"], depth=nd["depth"] + 1, parent=nid)
                     if shor:
                         nodes[cid]["shor"] = child_shor
+                    if nd.get("state") is not None:
+                        nodes[cid]["pstate"] = nd["state"]
                     heapq.heappush(heap, (nd["LB"], cid)); heapq.heappush(lbheap, (nd["LB"], cid)); fifo.append(cid)
         # prune dominated nodes (OMC.jl:1220-1244): the open set can only gain dominated nodes when the incumbent improved, so the scan the
         # reference repeats every iteration runs only then; the global lower bound (OMC.jl:1207-1218) is the smallest live entry of a

@@ -98,6 +98,8 @@ struct omc_instance {
   DevBuf sgInts, sgBytes, sgGroups, sgNodeGroup, sAh, sX, sW, sTh, sV1, sV2, sV3, sD0, sP0, sMbufB, sVrowB, sTq, sPq, sNq, sD5x, sD5t, snu5, sP5x,
       scolpart, sminpart, sminpart2, sfroB, svvB, se1, se2, soX, soW, soTh, sbigscr, sXsB, ssubSB, ssubIB;
   long long big_sub_tot[8] = {0};
+  // warm-start pool (omc_state_pool_create / omc_relax_set_warm)
+  int pool_cap = 0; DevBuf pY, pD1, pD3, pU, palpha, psval, pXs, ptheta, pscal, bwarmL, bwarmS; std::vector<int> warm_load, warm_save;
   // kernel stats
   int64_t launches[OMC_KERNEL_NCLASS] = {0}; double ms[OMC_KERNEL_NCLASS] = {0}; int64_t units[OMC_KERNEL_NCLASS] = {0};
   size_t nnz_rows() const { return row_idx.size(); }
@@ -222,7 +224,8 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt,
                    &h->sgInts, &h->sgBytes, &h->sgGroups, &h->sgNodeGroup, &h->sAh, &h->sX, &h->sW, &h->sTh, &h->sV1, &h->sV2, &h->sV3, &h->sD0, &h->sP0, &h->sMbufB, &h->sVrowB,
                    &h->sTq, &h->sPq, &h->sNq, &h->sD5x, &h->sD5t, &h->snu5, &h->sP5x, &h->scolpart, &h->sminpart, &h->sminpart2, &h->sfroB, &h->svvB, &h->se1, &h->se2,
-                   &h->soX, &h->soW, &h->soTh, &h->sbigscr, &h->soV, &h->sXsB, &h->ssubSB, &h->ssubIB};
+                   &h->soX, &h->soW, &h->soTh, &h->sbigscr, &h->soV, &h->sXsB, &h->ssubSB, &h->ssubIB,
+                   &h->pY, &h->pD1, &h->pD3, &h->pU, &h->palpha, &h->psval, &h->pXs, &h->ptheta, &h->pscal, &h->bwarmL, &h->bwarmS};
   for (DevBuf* b : all) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -542,6 +545,16 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.oobj = os; w.olb = os + sN; w.olmin = os + 2 * sN; w.orho = os + 4 * sN;
     w.ostatus = h->boint.as<int>(); w.oiters = h->boint.as<int>() + sN;
   }
+  // warm-start indices of this batch (consumed: they belong to this stage call only)
+  w.load_from = nullptr; w.save_to = nullptr;
+  if (h->pool_cap > 0 && !shor && (h->warm_load.size() == (size_t)B || h->warm_save.size() == (size_t)B)) {
+    if (h->warm_load.size() == (size_t)B) { if ((rc_ = upload(h->bwarmL, h->warm_load.data(), sizeof(int) * B, h->stream))) return rc_; w.load_from = h->bwarmL.as<int>(); }
+    if (h->warm_save.size() == (size_t)B) { if ((rc_ = upload(h->bwarmS, h->warm_save.data(), sizeof(int) * B, h->stream))) return rc_; w.save_to = h->bwarmS.as<int>(); }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    w.pY = h->pY.as<double>(); w.pD1 = h->pD1.as<double>(); w.pD3 = h->pD3.as<double>(); w.pU = h->pU.as<double>(); w.palpha = h->palpha.as<double>();
+    w.psval = h->psval.as<double>(); w.pXs = h->pXs.as<double>(); w.ptheta = h->ptheta.as<double>(); w.pscal = h->pscal.as<double>();
+  }
+  h->warm_load.clear(); h->warm_save.clear();
   // Q upload
   {
     std::vector<double> hQ(sN * n * rmax, 0.0);
@@ -657,6 +670,35 @@ int omc_set_node_rho_scales(omc_instance* h, int B, const double* rho_scale) {
   if (!h || B <= 0 || !rho_scale) return fail(OMC_ERR_ARGUMENT, "NULL argument");
   for (int b = 0; b < B; ++b) if (!(rho_scale[b] > 0.0)) return fail(OMC_ERR_ARGUMENT, "rho_scale must be positive");
   h->rho_scale_per_node.assign(rho_scale, rho_scale + B);
+  return 0;
+}
+
+// ---- warm start: a child is its parent plus one cut.  The caller keeps a pool of final states on the device and tells the
+// next staged batch which entry each node starts from (its parent's) and where its own final state goes.  The reference rebuilds and cold-starts
+// every model (OMC.jl:1482); this is an addition of the engine, off unless asked for.
+int omc_state_pool_create(omc_instance* h, int capacity) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (capacity < 0) return fail(OMC_ERR_ARGUMENT, "capacity must be non-negative");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t c = (size_t)capacity, n = h->n, k = h->k, np16 = (h->n + 15) & ~15;
+  if (capacity > 0) {
+    ENS(h->pY, c * n * n * 8); ENS(h->pD1, c * n * n * 8); ENS(h->pD3, c * n * n * 8); ENS(h->pU, c * n * k * 8); ENS(h->palpha, c * (size_t)h->nnz * 8);
+    ENS(h->psval, c * (size_t)h->m * 8); ENS(h->pXs, c * np16 * 16 * 8); ENS(h->ptheta, c * 16 * 8); ENS(h->pscal, c * 4 * 8);
+  }
+  h->pool_cap = capacity;
+  return 0;
+}
+
+int omc_relax_set_warm(omc_instance* h, int B, const int* load_from, const int* save_to) {
+  if (!h || B <= 0) return fail(OMC_ERR_ARGUMENT, "omc_relax_set_warm: bad arguments");
+  if (h->pool_cap <= 0) return fail(OMC_ERR_ARGUMENT, "omc_relax_set_warm: no state pool (omc_state_pool_create)");
+  h->warm_load.clear(); h->warm_save.clear();
+  for (int b = 0; b < B; ++b) {
+    if (load_from && load_from[b] >= h->pool_cap) return fail(OMC_ERR_ARGUMENT, "load_from index beyond the pool");
+    if (save_to && save_to[b] >= h->pool_cap) return fail(OMC_ERR_ARGUMENT, "save_to index beyond the pool");
+  }
+  if (load_from) h->warm_load.assign(load_from, load_from + B);
+  if (save_to) h->warm_save.assign(save_to, save_to + B);
   return 0;
 }
 
@@ -883,6 +925,7 @@ int omc_relax_solve(omc_instance* h) {
     if (nfin) {
       int rc = push_flags(init, fin); if (rc) return rc;
       TIMED(OMC_KERNEL_HARVEST, nfin, {
+        if (w.save_to) omc_launch_state_save(&w, s);                              // warm-start pool: before the recovery overwrites the iterate U = Q Vt
         omc_launch_small(&w, SMALL_RECOVER, h->small_use_lds, h->small_lds, s);   // a U with U U' <= Y and the same Q'U
         if (w.sep_done) omc_launch_sep_sub(&w, s);                                // separation vector from the tracked block where there is one
         omc_launch_cone(&w, CONE_SEP, h->cone_use_lds, h->cone_lds, s);           // separation vector (OMC.jl:2466-2477)

@@ -91,6 +91,9 @@ struct OmcWS {
   const double *shP0, *shD0;   // B * shN * shN
   double clip_hi;         // upper clip of the cone kernels (1 for 0 <= Y <= I; 1e300 for the big cone's PSD projection)
   double inv_s2;          // 1 / scale^2: the Shor solve runs on scale * A, objective and bound are reported unscaled (1 otherwise)
+  // warm start from a parent's final state (omc_state_pool_create / omc_relax_set_warm): per-node pool indices (-1: cold / not saved)
+  const int *load_from, *save_to;      // Btot each, or NULL
+  double *pY, *pD1, *pD3, *pU, *palpha, *psval, *pXs, *ptheta, *pscal;   // pool: strides n*n, n*n, n*n, n*k, nnz, m, np16*16, 16, 4 (rho, sub_on, -, -)
   int* sub_stat;          // B * 8: calls, power steps, failures (fall back to the full decomposition), seeds, failures by cause (too many positive Ritz values, step cap, Cholesky), Rayleigh-Ritz passes
   // rows
   int* R;                 // B
@@ -141,6 +144,7 @@ void omc_launch_cert_sub(const OmcWS* w, hipStream_t s);
 void omc_launch_sep_sub(const OmcWS* w, hipStream_t s);
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s);
 void omc_launch_harvest(const OmcWS* w, hipStream_t s);
+void omc_launch_state_save(const OmcWS* w, hipStream_t s);
 void omc_launch_aa(const OmcWS* w, hipStream_t s);
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s);
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s);

@@ -69,6 +69,56 @@ __global__ void k_setup(OmcWS w) {
   double* Y = w.Y + (size_t)b * n * n;
   double* Yp = w.Yp + (size_t)b * n * n;
   const double d0 = (double)k / (double)n;
+  // warm start: the parent's final state (pool entry lf) instead of the cold start.  The child keeps its own base penalty, so the parent's scaled
+  // duals are rescaled by rho_parent / rho_child; Yp = Y; U = Q_child Q_child' U_parent (the parent's rows are a prefix of the child's, so this
+  // is the parent's Vt padded with a zero for the new direction); small-cone duals and row multipliers start from zero; the tracked block of
+  // the cone follows (it is the eigen-space of Y - D1, which the rescaling only changes when the parent's penalty had been bumped)
+  const int lf = w.load_from ? w.load_from[nb] : -1;
+  const bool warm = lf >= 0;
+  const int NP = w.np16;
+  const int rc = w.rr[nb];
+  const double* Qc = w.Qb + (size_t)nb * n * rm;
+  if (warm) {
+    const double fw = w.pscal[(size_t)lf * 4] / w.rho_node[nb];
+    double fr2 = 0.0, tr1 = 0.0;
+    for (int e = tid; e < n * n; e += T) {
+      const int i = e % n, j = e / n;
+      const double y = w.pY[(size_t)lf * n * n + e], d1 = w.pD1[(size_t)lf * n * n + e] * fw;
+      Y[e] = y; Yp[e] = y;
+      w.D1[(size_t)b * n * n + e] = d1; w.D3[(size_t)b * n * n + e] = w.pD3[(size_t)lf * n * n + e] * fw; w.E3[(size_t)b * n * n + e] = 0.0;
+      const double mv = y - d1;
+      w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv; if (i == j) tr1 += mv;
+    }
+    for (int e = tid; e < NP * NP; e += T) {
+      const int i = e % NP, j = e / NP;
+      if (i >= n || j >= n) w.Mbuf[(size_t)b * NP * NP + e] = 0.0;
+      w.Vrow[(size_t)b * NP * NP + e] = 0.0;
+    }
+    for (int e = tid; e < NP * 16; e += T) w.Xs[(size_t)b * NP * 16 + e] = w.pXs[(size_t)lf * NP * 16 + e];
+    if (tid < 16) w.sub_theta[(size_t)b * 16 + tid] = w.ptheta[(size_t)lf * 16 + tid];
+    fr2 = block_sum(fr2, red); tr1 = block_sum(tr1, red);
+    if (tid == 0) {
+      w.fro2[b] = fr2; w.trM[b] = tr1; w.sub_on[b] = (w.sub_enable && w.pscal[(size_t)lf * 4 + 1] != 0.0) ? 1 : 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.v3valid[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
+    }
+    // Vt = Q_child' U_parent, U = Q_child Vt
+    for (int e = tid; e < rm * k; e += T) {
+      const int a = e % rm, j = e / rm;
+      double v = 0.0;
+      if (a < rc) for (int i = 0; i < n; ++i) v += Qc[(size_t)a * n + i] * w.pU[(size_t)lf * n * k + (size_t)j * n + i];
+      w.Vt[(size_t)b * rm * k + e] = v; w.D3V[(size_t)b * rm * k + e] = 0.0;
+      w.W3V[(size_t)b * rm * k + e] = 0.0; w.Q3V[(size_t)b * rm * k + e] = 0.0;
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int e = tid; e < n * k; e += T) {
+      const int i = e % n, j = e / n;
+      double v = 0.0;
+      for (int a = 0; a < rc; ++a) v += Qc[(size_t)a * n + i] * w.Vt[(size_t)b * rm * k + (size_t)j * rm + a];
+      w.U[(size_t)b * n * k + e] = v;
+    }
+    for (int e = tid; e < w.nnz; e += T) w.alpha[(size_t)b * w.nnz + e] = w.palpha[(size_t)lf * w.nnz + e];
+    for (int e = tid; e < w.m; e += T) w.sval[(size_t)b * w.m + e] = w.psval[(size_t)lf * w.m + e];
+  } else {
   for (int e = tid; e < n * n; e += T) {
     int i = e % n, j = e / n;
     double v = (i == j) ? d0 : 0.0;
@@ -76,7 +126,6 @@ __global__ void k_setup(OmcWS w) {
     w.D1[(size_t)b * n * n + e] = 0.0; w.D3[(size_t)b * n * n + e] = 0.0; w.E3[(size_t)b * n * n + e] = 0.0;
   }
   {
-    const int NP = w.np16;
     for (int e = tid; e < NP * NP; e += T) {
       int i = e % NP, j = e / NP;
       w.Mbuf[(size_t)b * NP * NP + e] = (i == j && i < n) ? d0 : 0.0;
@@ -91,12 +140,13 @@ __global__ void k_setup(OmcWS w) {
     w.Vt[(size_t)b * rm * k + e] = 0.0; w.D3V[(size_t)b * rm * k + e] = 0.0;
     w.W3V[(size_t)b * rm * k + e] = 0.0; w.Q3V[(size_t)b * rm * k + e] = 0.0;
   }
+  for (int e = tid; e < w.nnz; e += T) w.alpha[(size_t)b * w.nnz + e] = 0.0;
+  for (int e = tid; e < w.m; e += T) w.sval[(size_t)b * w.m + e] = -1.0;
+  }
   for (int e = tid; e < k * k; e += T) {
     w.D3T[(size_t)b * k * k + e] = 0.0; w.Q3T[(size_t)b * k * k + e] = 0.0;
     w.W3T[(size_t)b * k * k + e] = ((e % k) == (e / k)) ? 1.0 : 0.0;
   }
-  for (int e = tid; e < w.nnz; e += T) w.alpha[(size_t)b * w.nnz + e] = 0.0;
-  for (int e = tid; e < w.m; e += T) w.sval[(size_t)b * w.m + e] = -1.0;
   const int R = w.R[nb];
   for (int e = tid; e < w.Rmax; e += T) w.lam[(size_t)b * w.Rmax + e] = 0.0;
   if (tid == 0) {
@@ -2491,6 +2541,25 @@ __global__ void __launch_bounds__(256) k_harvest(OmcWS w) {
   }
 }
 
+// warm-start pool: the final state of the slots flagged fin whose node asked for it (runs BEFORE the recovery of a feasible U overwrites the iterate U = Q Vt)
+__global__ void __launch_bounds__(256) k_state_save(OmcWS w) {
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  if (!w.fin[b]) return;
+  const int nb = w.node_of[b];
+  const int sv = w.save_to ? w.save_to[nb] : -1;
+  if (sv < 0) return;
+  const int n = w.n, k = w.k, NP = w.np16;
+  for (int e = tid; e < n * n; e += T) {
+    w.pY[(size_t)sv * n * n + e] = w.Y[(size_t)b * n * n + e]; w.pD1[(size_t)sv * n * n + e] = w.D1[(size_t)b * n * n + e]; w.pD3[(size_t)sv * n * n + e] = w.D3[(size_t)b * n * n + e];
+  }
+  for (int e = tid; e < n * k; e += T) w.pU[(size_t)sv * n * k + e] = w.U[(size_t)b * n * k + e];
+  for (int e = tid; e < w.nnz; e += T) w.palpha[(size_t)sv * w.nnz + e] = w.alpha[(size_t)b * w.nnz + e];
+  for (int e = tid; e < w.m; e += T) w.psval[(size_t)sv * w.m + e] = w.sval[(size_t)b * w.m + e];
+  for (int e = tid; e < NP * 16; e += T) w.pXs[(size_t)sv * NP * 16 + e] = w.Xs[(size_t)b * NP * 16 + e];
+  if (tid < 16) w.ptheta[(size_t)sv * 16 + tid] = w.sub_theta[(size_t)b * 16 + tid];
+  if (tid == 0) { w.pscal[(size_t)sv * 4] = w.rho_b[b]; w.pscal[(size_t)sv * 4 + 1] = w.sub_on[b] ? 1.0 : 0.0; w.pscal[(size_t)sv * 4 + 2] = 0.0; w.pscal[(size_t)sv * 4 + 3] = 0.0; }
+}
+
 __global__ void k_zero_check(OmcWS w) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= w.B || w.done[b]) return;
@@ -2608,6 +2677,7 @@ void omc_launch_check_final(const OmcWS* w, int last, int phase, hipStream_t s) 
 }
 void omc_launch_rho_rescale(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_rho_rescale, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_harvest(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_harvest, dim3(w->B), dim3(256), 0, s, *w); }
+void omc_launch_state_save(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_state_save, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_aa(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_aa, dim3(w->nB), dim3(512), 0, s, *w); }
 void omc_launch_make_X(const OmcWS* w, double* X, hipStream_t s) { hipLaunchKernelGGL(k_make_X, dim3(64, w->Btot), dim3(256), 0, s, *w, X); }
 void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStream_t s) {

@@ -647,10 +647,13 @@ def sdp_relaxation(inst, cuts=(), cut_type="linear", U_lower=None, U_upper=None,
         AU[rr] = rows.CU[rr].ravel()
     G1 = (AY / wY1.ravel()) @ AY.T + (AU / 2.0) @ AU.T          # Gram matrix for rho = 1
     if warm is not None:
-        Y = warm["Y"].copy(); Vt = Q.T @ warm["U"]; Yp = warm.get("Yp", Y).copy()
+        # warm start from the parent's final state (round 3; mirrored by k_setup in omc_device.hip): the child keeps its own base penalty,
+        # so the parent's scaled duals are rescaled by rho_parent / rho_child (the multipliers rho D stay what they were); Yp = Y;
+        # the small-cone duals and the row multipliers start from zero (the child has a row basis of its own: one more cut)
+        Y = warm["Y"].copy(); Vt = Q.T @ warm["U"]; Yp = Y.copy()
         alpha = [a.copy() for a in warm["alpha"]]; svals = list(warm["svals"])
-        D1 = warm["D1"].copy(); D3 = warm["D3"].copy()
-        rho = warm.get("rho", rho) if p.rho_init <= 0 else rho
+        f_w = float(warm.get("rho", rho)) / rho
+        D1 = warm["D1"] * f_w; D3 = warm["D3"] * f_w
     else:
         Y = np.eye(n) * (k / n); Vt = np.zeros((r, k)); Yp = Y.copy()
         alpha = [np.zeros_like(a) for (_, _, _, a) in inst.groups]; svals = [None] * len(inst.groups)

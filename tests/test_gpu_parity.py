@@ -913,3 +913,64 @@ def test_stalled_nodes_certified_at_the_relaxed_residual_pass_the_primal_residua
         assert abs(o["objective"] - o["dual_bound"]) <= 1.01e-6 * max(1.0, abs(o["objective"]))
     assert nopt >= len(nodes) // 2
     eng.close()
+
+
+# ---- round 3: warm start from the parent's final state (omc_state_pool_create / omc_relax_set_warm) ----------------------------------------
+def test_warm_start_same_optimum_fewer_iterations_and_oracle_mirror(have_gpu, omc, orc):
+    """A child is its parent plus one cut.  Warm-started from the parent's final state it must reach the same certified value as from a cold
+    start (same convex program, 2e-6 on certified nodes), the oracle's warm start (same state transfer: Y, rescaled duals of the two full
+    cones, column multipliers, U) must agree with the GPU's, and along a depth-4 path the warm solves need fewer iterations in total."""
+    A, mask = orc.make_instance(24, 28, 1, seed=12, kind="lowrank", n_indices=int(0.4 * 24 * 28), noise=0.2)
+    inst = orc.Instance(A, mask, GAMMA, 1)
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    eng.state_pool_create(8)
+    P = omc.default_params(rho_scale=4.0)
+    OP = orc.RelaxParams(rho_scale=4.0)
+    cuts = []; it_cold = it_warm = 0
+    g = eng.matrix_completion_SDP_relaxation([cuts], "linear", params=P, save_to=[0])[0]
+    o = orc.sdp_relaxation(inst, cuts, "linear", params=OP, want_certificate=False)
+    for d in range(4):
+        cuts = cuts + [(g["breakpoint_vec"].copy(), g["U"].copy(), ["left" if d % 2 == 0 else "right"])]
+        cold = eng.matrix_completion_SDP_relaxation([cuts], "linear", params=P)[0]
+        warm = eng.matrix_completion_SDP_relaxation([cuts], "linear", params=P, load_from=[d], save_to=[d + 1])[0]
+        ow = orc.sdp_relaxation(inst, cuts, "linear", params=OP, want_certificate=False, warm=o["warm"])
+        assert warm["status_code"] == 0 and ow["termination_status"] == orc.OMC_OPTIMAL
+        assert warm["objective"] == pytest.approx(ow["objective"], rel=OBJ_REL)
+        if cold["status_code"] == 0:
+            assert warm["objective"] == pytest.approx(cold["objective"], rel=OBJ_REL)
+        assert abs(warm["objective"] - warm["dual_bound"]) <= 1.01e-6 * max(1.0, abs(warm["objective"]))
+        assert abs(warm["iters"] - ow["iters"]) <= 50                      # same transfer, same splitting (the tracked block makes projections inexact)
+        it_cold += cold["iters"]; it_warm += warm["iters"]
+        g = warm; o = ow
+    assert it_warm < it_cold
+    eng.close()
+
+
+def test_warm_start_mixed_batch_through_few_slots_and_argument_checks(have_gpu, omc, orc):
+    """Warm and cold nodes in one batch, more nodes than slots (a slot is re-initialised from the pool for its next node); every node's
+    value equals its cold value; indices beyond the pool and a missing pool are argument errors."""
+    A, mask = orc.make_instance(20, 24, 1, seed=3, kind="readme")
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    P = omc.default_params(rho_scale=16.0, slots=3)
+    with pytest.raises(omc.OmcError) as e:
+        eng.stage([[]], "linear", P, load_from=[0])                        # no pool yet
+    assert e.value.code == -3
+    eng.state_pool_create(4)
+    root = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P, save_to=[2])[0]
+    kids = omc.pkg.bnb.make_children([], root, "linear", 1)
+    lvl1 = eng.matrix_completion_SDP_relaxation(kids, "linear", params=P, load_from=[2, 2], save_to=[0, 1])
+    gk = []; lf = []
+    for i, (c, o) in enumerate(zip(kids, lvl1)):
+        for c2 in omc.pkg.bnb.make_children(c, o, "linear", 1):
+            gk.append(c2); lf.append(i if len(gk) % 3 else -1)            # every third grandchild starts cold
+    warm = eng.matrix_completion_SDP_relaxation(gk, "linear", params=P, load_from=lf)
+    cold = eng.matrix_completion_SDP_relaxation(gk, "linear", params=P)
+    for w_, c_ in zip(warm, cold):
+        assert_finite(w_)
+        if w_["status_code"] == 0 and c_["status_code"] == 0:
+            assert w_["objective"] == pytest.approx(c_["objective"], rel=OBJ_REL)
+        assert w_["dual_bound"] <= c_["objective"] * (1 + 1e-5) + 1e-9 and c_["dual_bound"] <= w_["objective"] * (1 + 1e-5) + 1e-9   # both bounds valid for the same program
+    with pytest.raises(omc.OmcError) as e:
+        eng.stage(gk, "linear", P, load_from=[4] * len(gk))                # beyond the pool
+    assert e.value.code == -3
+    eng.close()
