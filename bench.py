@@ -232,6 +232,9 @@ def main():
     for _ in range(args.warmup):
         step()
     kstats = {}; sub = {}
+    markers = bool(os.environ.get("OMC_BENCH_MARKERS"))          # profiling runs: one k_eval_objective launch before and one after the timed steps
+    if markers:                                                   # (nothing else in this command launches it), so that a kernel trace can be cut to them
+        eng.evaluate_objective(A)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -247,6 +250,8 @@ def main():
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
+    if markers:
+        eng.evaluate_objective(A)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -8,10 +8,19 @@ def short(name):
     return name.replace("(OmcWS)", "").replace("(OmcWS, int)", "").replace("void ", "").strip()
 
 mode, d, out = sys.argv[1], sys.argv[2], sys.argv[3]
-if mode == "stats":
+if mode in ("stats", "stats-between"):
+    # stats-between <marker>: only the launches between the first and the second launch of the marker kernel (bench.py with
+    # OMC_BENCH_MARKERS=1 brackets its timed steps with k_eval_objective), so that the averages describe the launches the HIP events time
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     acc = defaultdict(lambda: [0, 0, 10**18, 0])
-    for r in csv.DictReader(open(f)):
+    rows_ = list(csv.DictReader(open(f)))
+    if mode == "stats-between":
+        marker = sys.argv[4]
+        rows_.sort(key=lambda r: int(r["Start_Timestamp"]))
+        marks = [int(r["Start_Timestamp"]) for r in rows_ if marker in r["Kernel_Name"]]
+        assert len(marks) >= 2, "marker kernel launched fewer than twice"
+        rows_ = [r for r in rows_ if marks[0] < int(r["Start_Timestamp"]) < marks[1]]
+    for r in rows_:
         t = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a = acc[r["Kernel_Name"]]
         a[0] += 1; a[1] += t; a[2] = min(a[2], t); a[3] = max(a[3], t)
     tot = sum(a[1] for a in acc.values())
