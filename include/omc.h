@@ -172,7 +172,11 @@ int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int*
  * Nodes with identical lists share one index structure on the device (the static mode hands every node the same list).
  * Everything else as omc_relax_stage; then omc_relax_solve / omc_relax_submit / _wait and omc_relax_fetch as usual (X and Theta are
  * the explicit variables of the Shor program), plus omc_relax_fetch_shor for W (OMC.jl:1908) and omc_relax_fetch_shor_V for V1, V2, V3.  Status, objective (recomputed as OMC.jl:1960-1967 does) and the certified dual bound as in the base mode.
- * rank k > 1 (Xt, Wt, H: OMC.jl:1526-1551, 1780-1827) returns OMC_ERR_UNSUPPORTED. */
+ * Rank k > 1 (Xt, Wt, H, per-layer blocks, one order-(k+1) block per coordinate: OMC.jl:1491-1494, 1526-1551, 1780-1827): reference quirk Q5 -- the slack
+ * that H cancels in W = sum Wt + 2 sum H makes every per-layer order-5 block satisfiable, so in that form the minors do not constrain (X, W); the
+ * program has the value of the same program without its order-5 blocks and with W >= X^2 kept on their coordinates.  That program is what is solved
+ * (same outputs); the lifted variables Xt, Wt, H, V1..V3 of the reference's result are an explicit extension of (X, W) (closed form, INTEGRATION.md;
+ * the host mirror api.py builds it), checked against the reference's full constraint set in the tests. */
 int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
                          const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
                          const double* U_upper, const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc,

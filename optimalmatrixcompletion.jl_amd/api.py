@@ -59,6 +59,36 @@ def _pack_cuts(nodes, n, k, cut_type):
     return L, cx, cU, cd
 
 
+def shor_rank_k_extension(k, X, W, minors):
+    """The lifted variables of the reference's rank k > 1 Shor form (Xt, Wt, H, V1, V2, V3: OMC.jl:1526-1551, results at 1909-1917) as an explicit
+    extension of the relaxation's (X, W).  Reference quirk Q5: in that form the slack s that H cancels in W = sum Wt + 2 sum H makes every
+    per-layer order-5 block satisfiable, so the minors do not constrain (X, W) and the engine solves the program without them; this is the closed form
+        Xt_1 = X, Xt_t = 0;  Wt_1 = X^2 + (W - X^2) + s, Wt_t = s/(k-1);  H_(1,t) = -s/(k-1), H_(t,t') = 0;  V^1 = products of X (V3: their mean), V^t = 0,
+        s_c = max over the minors that contain c of |X_{i1j2} X_{i2j1} - X_{i1j1} X_{i2j2}| / 2.
+    Returns Xt (k, n, m), Wt (k, n, m), H (k, k, n, m) and V (k, nq, 5) with the five products of each minor in the order of omc_relax_fetch_shor_V."""
+    X = np.asarray(X, float); W = np.asarray(W, float); n, m = X.shape
+    mi = np.asarray(minors, np.int64).reshape(-1, 4) - 1
+    nq = len(mi)
+    Xt = np.zeros((k, n, m)); Xt[0] = X
+    Wt = np.zeros((k, n, m)); H = np.zeros((k, k, n, m)); V = np.zeros((k, nq, 5))
+    if nq == 0:
+        return dict(Xt=Xt, Wt=Wt, H=H, V=V)
+    ci = np.stack([mi[:, 0], mi[:, 0], mi[:, 1], mi[:, 1]], 1); cj = np.stack([mi[:, 2], mi[:, 3], mi[:, 2], mi[:, 3]], 1)
+    xs = X[ci, cj]
+    e = 0.5 * np.abs(xs[:, 1] * xs[:, 2] - xs[:, 0] * xs[:, 3])
+    s = np.zeros((n, m)); inC = np.zeros((n, m), bool)
+    for p_ in range(4):
+        np.maximum.at(s, (ci[:, p_], cj[:, p_]), e); inC[ci[:, p_], cj[:, p_]] = True
+    s = np.where(inC, s * (1.0 + 1e-12) + 1e-300, 0.0)
+    b = s / (k - 1)
+    Wt[0] = np.where(inC, X * X + np.maximum(W - X * X, 0.0) + s, 0.0)
+    for t in range(1, k):
+        Wt[t] = np.where(inC, b, 0.0); H[0, t] = np.where(inC, -b, 0.0)
+    V[0, :, 0] = xs[:, 0] * xs[:, 1]; V[0, :, 1] = xs[:, 2] * xs[:, 3]; V[0, :, 2] = xs[:, 0] * xs[:, 2]; V[0, :, 3] = xs[:, 1] * xs[:, 3]
+    V[0, :, 4] = 0.5 * (xs[:, 0] * xs[:, 3] + xs[:, 1] * xs[:, 2])
+    return dict(Xt=Xt, Wt=Wt, H=H, V=V)
+
+
 class Engine:
     """Device-resident instance + the four call sites of the reference driver."""
 
@@ -214,14 +244,17 @@ class Engine:
         if add_Shor_valid_inequalities:
             if shor_info is None:
                 raise ValueError("add_Shor_valid_inequalities = true needs node.Shor_info (OMC.jl:1508)")
-            self.stage_shor(nodes, shor_info, disjunctive_cuts_type, params, U_lower, U_upper, shor_penalties, keep_V=want_V)
+            self.stage_shor(nodes, shor_info, disjunctive_cuts_type, params, U_lower, U_upper, shor_penalties, keep_V=(want_V and self.k == 1))
             self.solve()
             out = self.fetch(want_Y, want_X, want_Theta)
             for r, Wb in zip(out, self.fetch_shor()):
                 r["W"] = Wb
-            if want_V:
+            if want_V and self.k == 1:
                 for r, Vb, (mi, _) in zip(out, self.fetch_shor_V(), shor_info):
                     r["V"] = Vb[:len(np.asarray(mi).reshape(-1, 4))]
+            elif want_V:                                   # rank k > 1: the lifted variables are an explicit extension of (X, W) (quirk Q5)
+                for r, (mi, _) in zip(out, shor_info):
+                    r.update(shor_rank_k_extension(self.k, r["X"], r["W"], mi))
             return out
         self.stage(nodes, disjunctive_cuts_type, params, U_lower, U_upper, rho_scales, load_from, save_to)
         self.solve()

@@ -193,7 +193,7 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     With world_size > 1 every rank runs the same host logic on the same tree, relaxes its round-robin shard of the popped nodes
     and the ranks exchange (class Comm) the small per-node records, a MIN all-reduce of the incumbent and -- only when it improved --
     the incumbent X from its owner; leaving the loop is decided collectively.
-    add_Shor_valid_inequalities (rank 1, one rank): every node carries node.Shor_info (OMC.jl:37-40).  Static mode (OMC.jl:646-669): the
+    add_Shor_valid_inequalities (one rank; rank k > 1 through reference quirk Q5, see api.shor_rank_k_extension): every node carries node.Shor_info (OMC.jl:37-40).  Static mode (OMC.jl:646-669): the
     class lists of generate_rank1_matrix_completion_Shor_constraints_indexes (on the device), thinned by the fraction with numpy's RNG
     (randsubseq, OMC.jl:652-655); iterative mode (OMC.jl:670-674, 956-967, 2495-2518): the root starts without minors and a split node
     adds, with probability p(depth), the update_Shor_indices_n_minors most violated minors of its X (generate_violated_Shor_minors on
@@ -217,8 +217,6 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     shor = bool(add_Shor_valid_inequalities)
     shor_classes = [int(c) for c in Shor_valid_inequalities_noisy_rank1_num_entries_present]
     if shor:
-        if k != 1:
-            raise NotImplementedError("Shor mode is built for rank 1 (the k > 1 form, OMC.jl:1526-1551, is not)")
         if world_size != 1:
             raise NotImplementedError("Shor mode of the driver counterpart runs on one rank (the violated-minor update needs the node's X)")
         if not 0.0 <= add_Shor_valid_inequalities_fraction <= 1.0:
@@ -455,7 +453,10 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                     pu = (min_update_Shor_indices_probability if nd["depth"] > shor_decay_depth
                           else max_update_Shor_indices_probability / (update_Shor_indices_probability_decay_rate ** nd["depth"]))
                     if rng.random() < pu:
-                        new = engine.generate_violated_Shor_minors(local[nid]["X"][None, :, :], shor_classes, [tuple(t) for t in child_shor.tolist()],
+                        # OMC.jl:2497 passes reshape(X, (1, n, m)) whatever k is: the score is the minor of X itself (also what the k > 1 extension
+                        # Xt_1 = X, Xt_t = 0 gives); the device routine takes (k, n, m)
+                        X3 = np.zeros((k, n, m)); X3[0] = local[nid]["X"]
+                        new = engine.generate_violated_Shor_minors(X3, shor_classes, [tuple(t) for t in child_shor.tolist()],
                                                                    int(update_Shor_indices_n_minors))
                         add = np.asarray([t for _, t in new], np.int64).reshape(-1, 4)
                         child_shor = np.concatenate([child_shor, add]) if len(add) else child_shor     # union (2504-2507): `new` excludes the existing ones

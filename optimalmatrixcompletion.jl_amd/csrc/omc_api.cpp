@@ -1104,7 +1104,6 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
                          const int64_t* n_shor, const int64_t* shor_idx, const int64_t* n_soc, const int64_t* soc_idx) {
   if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
   if (B <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
-  if (h->k != 1) return fail(OMC_ERR_UNSUPPORTED, "Shor mode is built for rank k = 1 (OMC.jl:1513-1525); the k > 1 form (Xt, Wt, H: OMC.jl:1526-1551, 1780-1827) is not");
   if (!n_shor || !n_soc) return fail(OMC_ERR_ARGUMENT, "n_shor / n_soc is NULL");
   const int n = h->n, m = h->m;
   if ((long long)n * m >= (1ll << 30)) return fail(OMC_ERR_UNSUPPORTED, "Shor mode: n * m too large for the 32-bit index structures");
@@ -1191,7 +1190,22 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
       if (first_unobs >= 0) { G.ctype[j] = 0; G.slackrow[j] = first_unobs; }
       else if (first_nonC >= 0) { G.ctype[j] = 1; G.slackrow[j] = first_nonC; }
     }
-    nqmax = std::max(nqmax, nq); nv1max = std::max(nv1max, G.nv1); nv2max = std::max(nv2max, G.nv2);
+    if (h->k > 1) {
+      // Reference quirk Q5 (oracle/omc_oracle_shor.py header): in the rank k > 1 form (OMC.jl:1526-1551, 1780-1827) the slack that H
+      // cancels in W = sum Wt + 2 sum H makes every per-layer order-5 block satisfiable, so the minors do not constrain (X, W); what remains of them
+      // is W >= X^2 on their coordinates (implied by the order-(k+1) block).  The program solved is therefore the one without order-5 blocks and
+      // with those coordinates on the SOC list; the lifted variables Xt, Wt, H, V of the result are an explicit extension (host side: api.py).
+      for (size_t e = 0; e < (size_t)n * m; ++e) if (G.eclass[e] == 2) G.eclass[e] = 1;
+      for (int j = 0; j < m; ++j) {
+        int first_unobs = -1;
+        for (int i = 0; i < n; ++i) if (!h->mask[(size_t)j * n + i]) { first_unobs = i; break; }
+        if (first_unobs >= 0) { G.ctype[j] = 0; G.slackrow[j] = first_unobs; } else { G.ctype[j] = 1; G.slackrow[j] = 0; }
+      }
+      G.nq = 0; G.nv1 = 0; G.nv2 = 0;
+      G.mi.clear(); G.kid.clear(); G.cent.clear(); G.v1ent.clear(); G.v2ent.clear();
+      G.cptr.assign((size_t)n * m + 1, 0); G.v1ptr.assign(1, 0); G.v2ptr.assign(1, 0);
+    }
+    nqmax = std::max(nqmax, G.nq); nv1max = std::max(nv1max, G.nv1); nv2max = std::max(nv2max, G.nv2);
     G.off_int = tot_int;
     tot_int += G.mi.size() + G.kid.size() + G.cptr.size() + G.cent.size() + G.v1ptr.size() + G.v1ent.size() + G.v2ptr.size() + G.v2ent.size() + G.slackrow.size();
     G.off_byte = tot_byte;
@@ -1262,7 +1276,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   HIPCHK(hipMemsetAsync(h->sminpart.p, 0, sB * nmb * 8, s));
   HIPCHK(hipMemsetAsync(h->sminpart2.p, 0, sB * nmb * 8, s));
   HIPCHK(hipMemsetAsync(h->soX.p, 0, sN * nm * 8, s)); HIPCHK(hipMemsetAsync(h->soW.p, 0, sN * nm * 8, s)); HIPCHK(hipMemsetAsync(h->soTh.p, 0, sN * m * m * 8, s));
-  sh.n = n; sh.m = m; sh.N = N; sh.NPb = NPb; sh.S = S; sh.Btot = B; sh.nqmax = nqmax; sh.nv1max = nv1max; sh.nv2max = nv2max; sh.nmb = nmb;
+  sh.n = n; sh.m = m; sh.k = h->k; sh.N = N; sh.NPb = NPb; sh.S = S; sh.Btot = B; sh.nqmax = nqmax; sh.nv1max = nv1max; sh.nv2max = nv2max; sh.nmb = nmb;
   sh.rx = w.relax; sh.r4 = h->shor_r4; sh.r5 = h->shor_r5; sh.gamma = h->gamma; sh.sc = sc;
   sh.groups = h->sgGroups.as<ShorGroupDev>(); sh.node_group = h->sgNodeGroup.as<int>();
   sh.node_of = w.node_of; sh.done = w.done; sh.init = w.init; sh.fin = w.fin; sh.rho_b = w.rho_b; sh.bfac = w.bfac;

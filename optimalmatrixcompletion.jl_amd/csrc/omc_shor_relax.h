@@ -30,7 +30,7 @@ struct ShorGroupDev {
 };
 
 struct ShWS {
-  int n, m, N, NPb, S, Btot, nqmax, nv1max, nv2max, nmb;   // nmb = minor blocks (256 minors each) per slot
+  int n, m, k, N, NPb, S, Btot, nqmax, nv1max, nv2max, nmb;   // nmb = minor blocks (256 minors each) per slot
   double rx, r4, r5, gamma, sc;
   const ShorGroupDev* groups; const int* node_group;       // Btot
   const int *node_of, *done, *init, *fin;                  // slot arrays of the base workspace

@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(SH_T) k_shor_harvest(ShWS w) {
 
 extern "C" {
 void omc_shor_launch_setup(const ShWS* w, hipStream_t s) {
-  hipLaunchKernelGGL(k_shor_setup, dim3(w->S), dim3(SH_T), 0, s, *w, 1.0 / (double)w->n);      // Y0 = (k / n) I with k = 1
+  hipLaunchKernelGGL(k_shor_setup, dim3(w->S), dim3(SH_T), 0, s, *w, (double)w->k / (double)w->n);      // Y0 = (k / n) I
 }
 void omc_shor_launch_minor_pre(const ShWS* w, hipStream_t s) {
   if (w->nqmax > 0) hipLaunchKernelGGL(k_shor_minor_pre, dim3(w->nmb, w->S), dim3(SH_T), 0, s, *w);

@@ -12,7 +12,14 @@ What is restated (OMC.jl = /root/reference/src/OptimalMatrixCompletion.jl), rank
     Th_jj = sum_i W_ij                               OMC.jl:1763-1767
     one order-5 PSD block per minor (i1,i2,j1,j2)    OMC.jl:1768-1779
     objective 1/2 sum_Omega (A^2 - 2AX + W) + tr(Th)/(2 gamma)   OMC.jl:1838-1846, 1960-1967
-The rank k > 1 form (Xt, Wt, H; OMC.jl:1491-1494, 1526-1551, 1780-1827) is NOT restated here.
+and rank k > 1 (Xt, Wt, H, per-layer order-5 blocks, one order-(k+1) block per coordinate, W = sum Wt + 2 sum H on the minor coordinates:
+OMC.jl:1491-1494, 1526-1551, 1780-1827).  REFERENCE QUIRK Q5: for k > 1 the minors do not constrain (X, W) at all.  With s >= 0 free,
+    Xt_1 = X, Xt_t = 0;  Wt_1 = X^2 + e + s, Wt_t = s/(k-1);  H_(1,t) = -s/(k-1), H_(t,t') = 0;  V^1 = the products of X (V3 = their mean), V^t = 0
+satisfies W = sum Wt + 2 sum H = X^2 + e, the order-(k+1) block (its Schur complement is [[e + s, -b 1'], [-b 1, b I]], b = s/(k-1): PSD for e >= 0), the
+layers t >= 2 trivially, and the layer-1 block of every minor as soon as s >= |X_{i1j2} X_{i2j1} - X_{i1j1} X_{i2j2}| / 2 at its four coordinates --
+the slack s that H cancels in W costs nothing.  So every (X, W) with W >= X^2 on the minor coordinates extends to a feasible point: the k > 1
+program has the value of the same program WITHOUT its minors (W >= X^2 kept on their coordinates, which the order-(k+1) block implies).
+`sdp_relaxation_shor` solves that and `complete_shor_rank_k` builds the extension; `shor_rank_k_residuals` checks the reference's full program on it.
 
 How it is solved (ours; the reference hands the program to Mosek).  Consensus ADMM with X explicit (Shor mode):
   * W is kept only on the coordinates that occur in a minor (set C).  Off C the program only needs the column sums:
@@ -199,8 +206,6 @@ def sdp_relaxation_shor(inst, shor_idx, soc_idx, cuts=(), cut_type="linear", U_l
     1838-1846).  `shor_idx`: (nq, 4) 1-based (i1, i2, j1, j2) = node.Shor_info.constraints_indexes; `soc_idx`: (ns, 2)
     1-based = node.Shor_info.SOC_constraints_indexes.  Returns the reference's keys (objective, Y, U, X, Theta, W, V1, V2, V3,
     termination_status, feasible, solve_time) plus dual_bound, iters, residuals."""
-    if inst.k != 1:
-        raise NotImplementedError("Shor mode: rank k > 1 (OMC.jl:1526-1551, 1780-1827) is not restated")
     if cut_type not in base.CUT_TYPES:
         raise ValueError("Invalid input for disjunctive cuts type (OMC.jl:1456-1462)")
     p = params or ShorParams()
@@ -208,7 +213,14 @@ def sdp_relaxation_shor(inst, shor_idx, soc_idx, cuts=(), cut_type="linear", U_l
     n, m, k, g = inst.n, inst.m, inst.k, inst.gamma
     N = n + m
     mask = inst.indices
-    st = ShorStructure(n, m, shor_idx, soc_idx, mask)
+    st_full = ShorStructure(n, m, shor_idx, soc_idx, mask)
+    if k > 1:
+        # quirk Q5 (header): the minors of the k > 1 form are vacuous; their coordinates keep W >= X^2 (implied by the order-(k+1) block)
+        keep = st_full.soc_list | st_full.inC
+        soc_k = [(i + 1, j + 1) for j in range(m) for i in range(n) if keep[i, j]]
+        st = ShorStructure(n, m, [], soc_k, mask)
+    else:
+        st = st_full
     nq = st.nq
     rows = build_rows(inst, cuts, cut_type, U_lower, U_upper, p.reference_quirk_q1)
     R = len(rows)
@@ -398,6 +410,11 @@ def sdp_relaxation_shor(inst, shor_idx, soc_idx, cuts=(), cut_type="linear", U_l
                hist=hist, rp=rp, rd=rd, rho=rho, structure=st, rows=rows, scale=sc)
     out["objective_reference_formula"] = base.compute_SDP_relaxation_objective(Xo, Tho, inst.A, inst.indices, g, W=Wo)
     out["residuals"] = shor_primal_residuals(inst, st, rows, Xo, Wo, out["V1"], out["V2"], out["V3"], Tho, Y, U)
+    if k > 1:
+        out["structure_full"] = st_full
+        out.update(complete_shor_rank_k(k, st_full, Xo, Wo))          # Xt, Wt, H, V1, V2, V3 of OMC.jl:1915-1917, 1909-1911
+        out["residuals_rank_k"] = shor_rank_k_residuals(k, st_full, Xo, Wo, out)
+        out["residuals"]["max"] = max(out["residuals"]["max"], out["residuals_rank_k"]["max"])
     return out
 
 
@@ -478,3 +495,72 @@ def driver_shor_lists(indices, num_entries_present=(4,), minors=None):
         cov[i1 - 1, j1 - 1] = cov[i1 - 1, j2 - 1] = cov[i2 - 1, j1 - 1] = cov[i2 - 1, j2 - 1] = True
     soc = [(i + 1, j + 1) for j in range(m) for i in range(n) if not cov[i, j]]     # column-major order of Iterators.product (663)
     return list(minors), soc
+
+
+# ----------------------------------------------------------------------------------------------------------
+# rank k > 1: the explicit extension of (X, W) to the reference's lifted variables (quirk Q5, header)
+# ----------------------------------------------------------------------------------------------------------
+def complete_shor_rank_k(k, st, X, W):
+    """Xt (k, n, m), Wt (k, n, m; meaningful on the minor coordinates), H (k, k, n, m; H[t1, t2] for t1 < t2), and per layer and minor the five
+    lifted products V[t, q] = (V1[i1,(j1,j2)], V1[i2,(j1,j2)], V2[(i1,i2),j1], V2[(i1,i2),j2], V3[(i1,i2),(j1,j2)]) of OMC.jl:1526-1551."""
+    n, m = X.shape
+    nq = st.nq
+    Xt = np.zeros((k, n, m)); Xt[0] = X
+    xs = X[st.ci, st.cj] if nq else np.zeros((0, 4))
+    e = 0.5 * np.abs(xs[:, 1] * xs[:, 2] - xs[:, 0] * xs[:, 3]) if nq else np.zeros(0)       # |X_{i1j2} X_{i2j1} - X_{i1j1} X_{i2j2}| / 2
+    s = np.zeros((n, m))
+    for p in range(4):
+        if nq:
+            np.maximum.at(s, (st.ci[:, p], st.cj[:, p]), e)
+    s = np.where(st.inC, s * (1.0 + 1e-12) + 1e-300, 0.0)
+    b = s / (k - 1)
+    Wt = np.zeros((k, n, m)); H = np.zeros((k, k, n, m))
+    slack = np.maximum(W - X * X, 0.0)                       # the column slack a minor coordinate may carry
+    Wt[0] = np.where(st.inC, X * X + slack + s, 0.0)
+    for t in range(1, k):
+        Wt[t] = np.where(st.inC, b, 0.0)
+        H[0, t] = np.where(st.inC, -b, 0.0)
+    V = np.zeros((k, nq, 5))
+    if nq:
+        V[0, :, 0] = xs[:, 0] * xs[:, 1]; V[0, :, 1] = xs[:, 2] * xs[:, 3]          # V1[i1,(j1,j2)], V1[i2,(j1,j2)]
+        V[0, :, 2] = xs[:, 0] * xs[:, 2]; V[0, :, 3] = xs[:, 1] * xs[:, 3]          # V2[(i1,i2),j1], V2[(i1,i2),j2]
+        V[0, :, 4] = 0.5 * (xs[:, 0] * xs[:, 3] + xs[:, 1] * xs[:, 2])              # V3: one value at (1,4) and (2,3)
+    return dict(Xt=Xt, Wt=Wt, H=H, V=V)
+
+
+def shor_rank_k_residuals(k, st, X, W, ext):
+    """Violation of the k > 1 Shor constraints of the reference (OMC.jl:1787-1826) on an extended point: X = sum_t Xt, W = sum Wt + 2 sum H on
+    the minor coordinates, Wt >= 0, the order-5 block of every (layer, minor), the order-(k+1) block of every minor coordinate."""
+    Xt, Wt, H, V = ext["Xt"], ext["Wt"], ext["H"], ext["V"]
+    res = {}
+    res["X_sum"] = float(np.abs(Xt.sum(0) - X).max())
+    Hs = sum(H[t1, t2] for t1 in range(k) for t2 in range(t1 + 1, k))
+    C = st.inC
+    res["W_sum"] = float(np.abs((Wt.sum(0) + 2.0 * Hs - W)[C]).max()) if C.any() else 0.0            # 1787-1791
+    res["Wt_nonneg"] = max(0.0, -float(Wt[:, C].min())) if C.any() else 0.0                           # 1528-1531
+    worst = 0.0
+    for t in range(k):                                                                                 # 1797-1809
+        if st.nq == 0:
+            break
+        M = np.zeros((st.nq, 5, 5)); M[:, 0, 0] = 1.0
+        xs = Xt[t][st.ci, st.cj]; ws = Wt[t][st.ci, st.cj]
+        for p in range(4):
+            M[:, 0, p + 1] = M[:, p + 1, 0] = xs[:, p]; M[:, p + 1, p + 1] = ws[:, p]
+        M[:, 1, 2] = M[:, 2, 1] = V[t, :, 0]; M[:, 3, 4] = M[:, 4, 3] = V[t, :, 1]
+        M[:, 1, 3] = M[:, 3, 1] = V[t, :, 2]; M[:, 2, 4] = M[:, 4, 2] = V[t, :, 3]
+        M[:, 1, 4] = M[:, 4, 1] = V[t, :, 4]; M[:, 2, 3] = M[:, 3, 2] = V[t, :, 4]
+        worst = max(worst, -float(np.linalg.eigvalsh(M)[:, 0].min()))
+    res["layer_minors"] = max(0.0, worst)
+    worst = 0.0
+    ii, jj = np.nonzero(C)                                                                             # 1810-1826
+    if len(ii):
+        B = np.zeros((len(ii), k + 1, k + 1)); B[:, 0, 0] = 1.0
+        for t in range(k):
+            B[:, 0, t + 1] = B[:, t + 1, 0] = Xt[t][ii, jj]; B[:, t + 1, t + 1] = Wt[t][ii, jj]
+        for t1 in range(k):
+            for t2 in range(t1 + 1, k):
+                B[:, t1 + 1, t2 + 1] = B[:, t2 + 1, t1 + 1] = H[t1, t2][ii, jj]
+        worst = -float(np.linalg.eigvalsh(B)[:, 0].min())
+    res["coordinate_blocks"] = max(0.0, worst)
+    res["max"] = max(res.values())
+    return res

@@ -196,12 +196,6 @@ def test_error_conditions(have_gpu, omc, orc):
         eng.fetch_shor_V()
     assert e.value.code == -3
     eng.close()
-    A2, mask2 = orc.make_instance(8, 9, 2, n_indices=50, seed=4, noise=0.2)
-    eng2 = omc.Engine(A2, mask2, GAMMA, 2)
-    with pytest.raises(omc.OmcError) as e:
-        eng2.stage_shor([[]], [([], None)])
-    assert e.value.code == -4                           # rank k > 1: OMC_ERR_UNSUPPORTED, not a silent fallback
-    eng2.close()
 
 
 def test_config3_full_size_with_the_real_class4_list_certified(have_gpu, omc, orc):
@@ -259,4 +253,28 @@ def test_branch_and_bound_with_shor_inequalities(have_gpu, omc, orc):
             assert lbs[0] >= plain["lower_bound"] - 1e-5 * abs(plain["lower_bound"])
         else:
             assert c.get("shor_updates", 0) >= 1 or c["nodes_relax_feasible_split"] == 0
+    eng.close()
+
+
+def test_rank2_shor_form_value_and_full_constraint_set(have_gpu, omc, orc, sh):
+    """Rank k = 2 with Shor inequalities (Xt, Wt, H, per-layer order-5 blocks, one order-3 block per coordinate: OMC.jl:1526-1551, 1780-1827).
+    Reference quirk Q5: the slack that H cancels in W = sum Wt + 2 sum H makes the minors vacuous, so the value is that of the program without
+    them.  Checked three ways: GPU = oracle at 2e-6; both = the base relaxation (every column has an unobserved entry); and the extended point
+    (Xt, Wt, H, V built by the host mirror from the GPU's (X, W)) satisfies EVERY constraint of the reference's k > 1 program."""
+    A, mask = orc.make_instance(12, 14, 2, n_indices=90, seed=3, noise=0.1)
+    inst = orc.Instance(A, mask, GAMMA, 2)
+    minors, soc = sh.driver_shor_lists(mask, (4,))
+    eng = omc.Engine(A, mask, GAMMA, 2)
+    r = eng.matrix_completion_SDP_relaxation([[]], "linear", omc.default_params(eps_gap=1e-6), add_Shor_valid_inequalities=True,
+                                             shor_info=[(minors, None)], want_Theta=True, want_V=True)[0]
+    ro = sh.sdp_relaxation_shor(inst, minors, soc, params=sh.ShorParams(eps_gap=1e-6))
+    rb = eng.matrix_completion_SDP_relaxation([[]], "linear", omc.default_params(rho_scale=4.0))[0]
+    assert r["status_code"] == 0 and ro["termination_status"] == 0 and rb["status_code"] == 0
+    assert r["objective"] == pytest.approx(ro["objective"], rel=OBJ_REL)
+    assert r["objective"] == pytest.approx(rb["objective"], rel=3e-6)
+    st = sh.ShorStructure(12, 14, minors, soc, mask)
+    res = sh.shor_rank_k_residuals(2, st, r["X"], r["W"], r)                 # the reference's k > 1 constraints on the GPU's extended point
+    assert res["max"] <= 1e-9, res
+    assert np.abs(np.diag(r["Theta"]) - r["W"].sum(0)).max() <= 1e-10
+    assert orc.compute_SDP_relaxation_objective(r["X"], r["Theta"], A, mask, GAMMA, W=r["W"]) == pytest.approx(r["objective"], rel=1e-9)
     eng.close()

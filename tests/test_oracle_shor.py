@@ -166,3 +166,24 @@ def test_slow_node_returns_values_and_a_valid_bound():
     assert r["termination_status"] in (orc.OMC_SLOW_PROGRESS, orc.OMC_OPTIMAL) and r["feasible"]
     assert r["dual_bound"] <= ub + 1e-6
     assert r["objective"] - r["dual_bound"] <= 5e-3 * r["objective"]
+
+
+def test_rank2_shor_minors_are_vacuous_and_the_extension_is_feasible():
+    """Reference quirk Q5 (k > 1 form, OMC.jl:1526-1551, 1780-1827): the value with all class-4 minors equals the value without any (and the
+    base relaxation's, every column having an unobserved entry), and the explicit extension (Xt, Wt, H, V) of the solution satisfies the
+    reference's full constraint set: X = sum Xt, W = sum Wt + 2 sum H, every per-layer order-5 block, every per-coordinate order-3 block."""
+    A, mask = orc.make_instance(10, 12, 2, n_indices=70, seed=6, noise=0.2)
+    inst = orc.Instance(A, mask, GAMMA, 2)
+    minors, soc = sh.driver_shor_lists(mask, (4,))
+    assert len(minors) > 100
+    r = sh.sdp_relaxation_shor(inst, minors, soc, params=sh.ShorParams(eps_gap=1e-6))
+    r0 = sh.sdp_relaxation_shor(inst, [], sh.driver_shor_lists(mask, minors=[])[1], params=sh.ShorParams(eps_gap=1e-6))
+    b = orc.sdp_relaxation(inst, params=orc.RelaxParams(rho_scale=4.0))
+    assert r["termination_status"] == orc.OMC_OPTIMAL and r0["termination_status"] == orc.OMC_OPTIMAL and b["termination_status"] == orc.OMC_OPTIMAL
+    assert r["objective"] == pytest.approx(r0["objective"], rel=1e-9)        # literally the same program after the reduction
+    assert r["objective"] == pytest.approx(b["objective"], rel=3e-6)
+    assert r["residuals_rank_k"]["max"] <= 1e-10, r["residuals_rank_k"]
+    # the extension really needs its slack: with s = 0 some layer-1 block of a minor with a non-vanishing determinant is indefinite
+    ext = sh.complete_shor_rank_k(2, r["structure_full"], r["X"], r["W"])
+    ext0 = dict(ext); ext0["Wt"] = ext["Wt"].copy(); ext0["Wt"][0] = np.where(r["structure_full"].inC, r["X"] ** 2, 0.0); ext0["Wt"][1] = 0.0; ext0["H"] = np.zeros_like(ext["H"])
+    assert sh.shor_rank_k_residuals(2, r["structure_full"], r["X"], r["W"], ext0)["layer_minors"] > 1e-6
