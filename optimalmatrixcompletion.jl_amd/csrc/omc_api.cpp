@@ -93,7 +93,7 @@ struct omc_instance {
   double shor_last_ms = 0; long long shor_last_candidates = 0;
   // Shor-mode relaxation (omc_relax_stage_shor): index structures of the distinct lists, explicit X / W / Theta state, view of the workspace
   // through which the base eigen-kernels project the order-(n+m) cone
-  bool shor_req = false, shor_on = false, shor_keep_V = false; DevBuf soV; double shor_rho = 0.05, shor_r4 = 0.0, shor_r5 = 2.0;      // r4 = 0: automatic per list
+  bool shor_req = false, shor_on = false, shor_keep_V = false, shor_via_base = false; std::vector<int> shor_slackrow; DevBuf soV; double shor_rho = 0.05, shor_r4 = 0.0, shor_r5 = 2.0;      // r4 = 0: automatic per list
   ShWS sh{}; OmcWS wbig{}; int big_lpp = 0, big_use_lds = 0, big_cone_lds_ok = 0; size_t big_lds = 0, big_cone_lds = 0;
   DevBuf sgInts, sgBytes, sgGroups, sgNodeGroup, sAh, sX, sW, sTh, sV1, sV2, sV3, sD0, sP0, sMbufB, sVrowB, sTq, sPq, sNq, sD5x, sD5t, snu5, sP5x,
       scolpart, sminpart, sminpart2, sfroB, svvB, se1, se2, soX, soW, soTh, sbigscr, sXsB, ssubSB, ssubIB;
@@ -287,7 +287,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   HIPCHK(hipSetDevice(h->device));
   h->staged = false;
   const bool shor = h->shor_req;      // set by omc_relax_stage_shor for this call only
-  h->shor_req = false; h->shor_on = false;
+  h->shor_req = false; h->shor_on = false; h->shor_via_base = false;
   if (params) h->params = *params; else omc_relax_params_default(&h->params);
   if (shor) {      // the bound of a Shor node lags its primal value for the first ~1000 iterations: no early stop, a longer stall window, one bump
     h->params.early_stop_factor = 0.0;
@@ -1212,6 +1212,20 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
     tot_byte += G.eclass.size() + G.ctype.size();
     tot_byte = (tot_byte + 15) & ~(size_t)15;
   }
+  // ---- rank k > 1 with an unobserved entry in every column: the program without order-5 blocks IS the base relaxation (theta_j >= x_j' Y^+ x_j
+  // implies theta_j >= ||x_j||^2 because Y <= I, and the slack of Theta_jj = sum_i W_ij sits on an unobserved entry at no cost): the base engine
+  // solves it (no order-(n+m) cone), omc_relax_fetch_shor completes W = X^2 + slack from its (X, Theta).
+  if (h->k > 1) {
+    bool all_free = true;
+    for (int g = 0; g < NG && all_free; ++g) for (int j = 0; j < m; ++j) if (gh[g].ctype[j] != 0) { all_free = false; break; }
+    if (all_free && !getenv("OMC_SHOR_EXPLICIT")) {
+      int rc0 = omc_relax_stage(h, B, params, cut_type, L, cut_x, cut_Uhat, cut_dir, U_lower, U_upper);
+      if (rc0) return rc0;
+      h->shor_via_base = true;
+      h->shor_slackrow = gh[0].slackrow;      // first unobserved row of every column (a property of the mask: the same for every list)
+      return 0;
+    }
+  }
   // ---- base staging (rows, small cone, clip, certificate machinery) with the Shor flag ----------------------------------------------
   h->shor_req = true;
   int rc = omc_relax_stage(h, B, params, cut_type, L, cut_x, cut_Uhat, cut_dir, U_lower, U_upper);
@@ -1369,6 +1383,20 @@ int omc_last_shor_subspace_stats(omc_instance* h, int64_t* out) {
 }
 
 int omc_relax_fetch_shor(omc_instance* h, double* W) {
+  if (h && h->staged && h->shor_via_base) {      // rank k > 1 served by the base engine: W = X^2, the slack Theta_jj - ||x_j||^2 on the column's first unobserved row
+    if (!W) return 0;
+    const size_t B = h->ws.Btot, n = h->n, m = h->m;
+    std::vector<double> X(B * n * m), Th(B * m * m);
+    int rc = omc_relax_fetch(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, X.data(), Th.data(), nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    for (size_t b = 0; b < B; ++b)
+      for (size_t j = 0; j < m; ++j) {
+        double s2 = 0.0;
+        for (size_t i = 0; i < n; ++i) { const double x = X[(b * m + j) * n + i]; W[(b * m + j) * n + i] = x * x; s2 += x * x; }
+        W[(b * m + j) * n + h->shor_slackrow[j]] += Th[(b * m + j) * m + j] - s2;
+      }
+    return 0;
+  }
   if (!h || !h->staged || !h->shor_on) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch_shor: no Shor-mode batch staged");
   HIPCHK(hipSetDevice(h->device));
   if (W) HIPCHK(hipMemcpyAsync(W, h->sh.oW, 8 * (size_t)h->sh.Btot * h->n * h->m, hipMemcpyDeviceToHost, h->stream));
