@@ -18,6 +18,7 @@ struct AltminWS {
   int *converged, *n_iters;
   double* mobj;            // B: master objective (OMC.jl:2352-2358) of X = U V, evaluated on the device from the factors
   double* G;               // B*Rmax*Rmax scratch
+  double* scratch; size_t scratch_stride;   // per-problem global slab that replaces the dynamic LDS when the problem does not fit it (NULL: LDS)
 };
 
 #ifdef __cplusplus

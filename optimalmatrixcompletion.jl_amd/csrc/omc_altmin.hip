@@ -36,7 +36,9 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 }
 
 __global__ void __launch_bounds__(256) k_altmin(AltminWS w) {
-  extern __shared__ double sm[];
+  extern __shared__ double sm_lds[];
+  // problems that do not fit the LDS (config 5: 1000 x 1000) keep the same state in a per-problem global slab (L2 / HBM): same code, flat addresses
+  double* sm = w.scratch ? w.scratch + (size_t)blockIdx.x * w.scratch_stride : sm_lds;
   __shared__ double red[32];
   __shared__ double s_Gp[NNQP_PMAX * (NNQP_PMAX + 1) / 2];
   __shared__ double s_sv[NNQP_PMAX], s_tmp[NNQP_PMAX];
@@ -221,7 +223,8 @@ __device__ __forceinline__ bool ak_inv(double (&a)[AK_KMAX][AK_KMAX], int k) {
 }
 
 __global__ void __launch_bounds__(256) k_altmin_k(AltminWS w) {
-  extern __shared__ double sm[];
+  extern __shared__ double sm_lds[];
+  double* sm = w.scratch ? w.scratch + (size_t)blockIdx.x * w.scratch_stride : sm_lds;
   __shared__ double red[32];
   __shared__ double s_Gp[NNQP_PMAX * (NNQP_PMAX + 1) / 2];
   __shared__ double s_sv[NNQP_PMAX], s_tmp[NNQP_PMAX];

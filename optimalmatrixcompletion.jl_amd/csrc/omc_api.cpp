@@ -63,7 +63,7 @@ struct omc_instance {
   std::vector<double> A; std::vector<uint8_t> mask;
   std::vector<double> Ncnt;
   std::vector<int> row_ptr, row_idx; std::vector<double> row_val;
-  DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arbj, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG;
+  DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arbj, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG, aG2;
   hipStream_t stream = nullptr;
   // per slot group: main / column / small-cone streams and fork, join, done events (see omc_relax_solve)
   hipStream_t gs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -75,7 +75,7 @@ struct omc_instance {
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
   DevBuf bobjcol, baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
   DevBuf bslotlist, bgap, bvotes, blamDX, bXsC, bsubSC, bsubIC;
-  DevBuf bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow, bXs, bsubS, bsubI;
+  DevBuf bsubz, bscal, bbx, bint, bcp, bcone, bglob, bXout, bThout, bXin, bMbuf, bVrow, bXs, bsubS, bsubI;
   long long sub_tot[8] = {0};
   int ws_lpp = 0, ws_use_lds = 0; size_t ws_lds = 0;
   OmcWS ws{};
@@ -218,9 +218,9 @@ void omc_instance_destroy(omc_instance* h) {
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
-                   &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes, &h->blamDX, &h->bXsC, &h->bsubSC, &h->bsubIC,
+                   &h->bsubz, &h->bscal, &h->bbx, &h->bint, &h->bcp, &h->bcone, &h->bglob, &h->bXout, &h->bThout, &h->bXin, &h->bMbuf, &h->bVrow, &h->bXs, &h->bsubS, &h->bsubI, &h->bslotlist, &h->bgap, &h->bvotes, &h->blamDX, &h->bXsC, &h->bsubSC, &h->bsubIC,
                    &h->brho, &h->brhon, &h->blamD, &h->bslotint, &h->boY, &h->boU, &h->boal, &h->bobx, &h->boscal, &h->boint, &h->drow_ptr, &h->drow_idx, &h->drow_val, &h->aR, &h->arkind, &h->arcut, &h->arbi, &h->arbj, &h->arcoef, &h->arrhs, &h->acutx,
-                   &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG,
+                   &h->aU0, &h->aU, &h->aV, &h->aobj, &h->aint, &h->aG, &h->aG2,
                    &h->bobjcol, &h->baaF, &h->baaG, &h->baaZ, &h->baaS, &h->baaI, &h->bMbufC, &h->bVrowC, &h->bchkS, &h->bchkI, &h->sbits, &h->scb, &h->scx, &h->scz, &h->soff, &h->stot, &h->sout, &h->shi, &h->slo, &h->sexist, &h->shist, &h->sohi, &h->solo, &h->scnt,
                    &h->sgInts, &h->sgBytes, &h->sgGroups, &h->sgNodeGroup, &h->sAh, &h->sX, &h->sW, &h->sTh, &h->sV1, &h->sV2, &h->sV3, &h->sD0, &h->sP0, &h->sMbufB, &h->sVrowB,
                    &h->sTq, &h->sPq, &h->sNq, &h->sD5x, &h->sD5t, &h->snu5, &h->sP5x, &h->scolpart, &h->sminpart, &h->sminpart2, &h->sfroB, &h->svvB, &h->se1, &h->se2,
@@ -619,6 +619,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       w.ws_ld = ldw;
       if (!h->ws_use_lds) {
         lpp = 16; rpl = (((n + 15) / 16) + 1) & ~1; Nrp = rpl * 16; ldw = Nrp + 2; w.ws_ld = ldw;
+        if (rpl > 32 && n <= 1024) { lpp = 64; rpl = (((n + 63) / 64) + 1) & ~1; Nrp = rpl * 64; ldw = Nrp + 2; w.ws_ld = ldw; }      // orders 513 .. 1024: a wave per pair
         const size_t need = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
         if (need / 8 + 8 > w.cone_scratch_stride) {
           w.cone_scratch_stride = need / 8 + 8;
@@ -629,7 +630,9 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       h->ws_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;   // WS_JROWS
       // subspace tracking needs the warm-started kernel as its seed / fall-back and at least 3 x 16 rows
       w.sub_enable = (h->ws_lpp && n >= 48 && omc_cone_sub_lds(w.np16) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE")) ? 1 : 0;
-      w.cert_enable = (w.sub_enable && w.MbufC && getenv("OMC_CERT_SUB")) ? 1 : 0;
+      w.sub_zscratch = nullptr;
+      if (w.sub_enable && w.np16 > 512) { ENS(h->bsubz, sB * 16 * (size_t)(w.np16 + 2) * 8); w.sub_zscratch = h->bsubz.as<double>(); }
+      w.cert_enable = (w.sub_enable && w.MbufC && (getenv("OMC_CERT_SUB") || w.np16 > 512)) ? 1 : 0;      // large orders: the certificate eigenvalues by the tracked block too (rigorous confirmation before anything is reported)
       w.sep_done = (w.sub_enable && !getenv("OMC_NO_SEP_SUB")) ? h->bsubIC.as<int>() + 2 * sB : nullptr;   // opt-in: measured no gain (the eigenvalues are not what the check spends its time on) and fewer rigorous samples of the bound
     }
     h->glob_lds = ((size_t)n * (n + 1) / 2 + (size_t)n * k + (size_t)rmax * k + 3 * Rmax + 8 + 16 * (size_t)n) * 8 + 16;   // packed lower triangle of the target; 16 = GL_XS staged cut vectors
@@ -1326,6 +1329,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
     size_t need = 0;
     if (!h->big_use_lds) {
       lpp = 16; rpl = (((N + 15) / 16) + 1) & ~1; Nrp = rpl * 16; ldw = Nrp + 2; wb.ws_ld = ldw;
+      if (rpl > 32 && N <= 1024) { lpp = 64; rpl = (((N + 63) / 64) + 1) & ~1; Nrp = rpl * 64; ldw = Nrp + 2; wb.ws_ld = ldw; }
       need = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
     }
     h->big_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
@@ -1351,6 +1355,8 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
     int* si = h->ssubIB.as<int>();
     sh.sub_onB = si; sh.cone_doneB = si + sB; sh.sub_waitB = si + 2 * sB; sh.sub_nfailB = si + 3 * sB;
     wb.sub_enable = 1; wb.Xs = h->sXsB.as<double>(); wb.sub_theta = h->ssubSB.as<double>();
+    wb.sub_zscratch = nullptr;
+    if (NPb > 512) { ENS(h->bsubz, sB * 16 * (size_t)(NPb + 2) * 8); wb.sub_zscratch = h->bsubz.as<double>(); }
     wb.sub_on = sh.sub_onB; wb.cone_done = sh.cone_doneB; wb.sub_wait = sh.sub_waitB; wb.sub_nfail = sh.sub_nfailB; wb.sub_stat = si + 4 * sB;
     wb.sep_done = nullptr;
   }
@@ -1565,8 +1571,16 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
   w.converged = h->aint.as<int>(); w.n_iters = h->aint.as<int>() + B; w.G = h->aG.as<double>(); w.mobj = h->amobj.as<double>();
   const size_t lds = (k == 1) ? ((size_t)4 * n + m + 2 * Rmax + 8) * 8
                               : ((size_t)4 * n * k + (size_t)2 * n * k * k + (size_t)k * m + 2 * Rmax + 8) * 8;
-  if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS - 8 * 1024 : (size_t)128 * 1024)) return fail(OMC_ERR_UNSUPPORTED, "omc_altmin_batch: n, m too large for the LDS-resident kernel of this round");
-  if (k == 1) omc_launch_altmin(&w, lds, s); else omc_launch_altmin_k(&w, lds, s);
+  w.scratch = nullptr; w.scratch_stride = 0;
+  size_t lds_launch = lds;
+  if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS - 8 * 1024 : (size_t)128 * 1024) || getenv("OMC_ALTMIN_NOLDS")) {
+    // the problem does not fit the LDS (config 5: 1000 x 1000, k = 2 needs 144 KB): the same kernel runs on a per-problem global slab
+    w.scratch_stride = lds / 8 + 8;
+    ENS(h->aG2, (size_t)B * w.scratch_stride * 8);
+    w.scratch = h->aG2.as<double>();
+    lds_launch = 0;
+  }
+  if (k == 1) omc_launch_altmin(&w, lds_launch, s); else omc_launch_altmin_k(&w, lds_launch, s);
   HIPCHK(hipMemcpyAsync(U, w.U, 8 * sB * n * k, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(V, w.V, 8 * sB * m * k, hipMemcpyDeviceToHost, s));
   if (objectives) HIPCHK(hipMemcpyAsync(objectives, w.objectives, 8 * sB * max_iters, hipMemcpyDeviceToHost, s));

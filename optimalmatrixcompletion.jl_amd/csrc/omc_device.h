@@ -76,6 +76,7 @@ struct OmcWS {
   // tracked top-16 subspace of the cone input (k_cone_sub): once Y has settled, clip(M, 0, 1) = sum over the FEW positive eigenpairs
   // (config 2: 2 of 100), so only the dominant invariant subspace is followed from one ADMM iteration to the next
   int sub_enable, sub_qmax, sub_chunk, sub_debug, sub_lazy; double sub_tol, sub_adapt;   // sub_lazy: orthonormalise once per chunk instead of after every power step
+  double* sub_zscratch;   // B * 16 * (np16 + 2): Z block of k_cone_sub for orders beyond 512 (NULL below)
   double* Xs;             // B * np16 * 16: orthonormal Ritz basis (column-major, ld = np16, zero padded rows)
   double* sub_theta;      // B * 16: Ritz values of the last accepted call
   double* trM;            // B: trace of Mbuf (with fro2 it bounds the untracked part of the spectrum)

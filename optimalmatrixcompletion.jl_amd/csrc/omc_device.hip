@@ -1041,7 +1041,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
           for (int i = 0; i < R2; ++i) {
             if (RPL2 || i < rpl2) { cp_[i] = gp[i * LPP]; cq_[i] = gq[i * LPP]; gm0 += cp_[i].x * cq_[i].x; gm1 += cp_[i].y * cq_[i].y; }
           }
-          double gm = group_sum_dpp<LPP>(gm0 + gm1);
+          double gm = (LPP == 64) ? wave_sum(gm0 + gm1) : group_sum_dpp<(LPP == 64) ? 16 : LPP>(gm0 + gm1);
           const double a = ev[p], bb = ev[q];
           const double g2 = gm * gm, ab = a * bb;
           if (g2 > tau2 * ab && ab > 0.0) {
@@ -1237,8 +1237,10 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   const int n = w.n, NP = w.np16, nt = NP >> 4, LD = NP + 2;
   const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   double* Xa = smem;                     // SUBP x LD   X (column j at Xa + j*LD)
-  double* Za = Xa + (size_t)SUBP * LD;   // SUBP x LD   Z = M X, then Y = Z + s X
-  double* Cs = Za + (size_t)SUBP * LD;   // 4 partial 16 x 16 products
+  // orders beyond 512 (config 5: n = 1000): the two SUBP x LD blocks no longer fit the LDS together -- Z lives in a per-slot global slab (L2) there
+  const bool zglob = NP > 512;
+  double* Za = zglob ? w.sub_zscratch + (size_t)b * SUBP * LD : Xa + (size_t)SUBP * LD;   // SUBP x LD   Z = M X, then Y = Z + s X
+  double* Cs = zglob ? Xa + (size_t)SUBP * LD : Za + (size_t)SUBP * LD;   // 4 partial 16 x 16 products
   double* Hs = Cs + 4 * 256;             // 16 x 17: Gram matrix / Cholesky factor / H / Ritz rotation
   double* Gj = Hs + 16 * 17;             // 16 x 17: Jacobi work
   double* th = Gj + 16 * 17;             // 16 Ritz values
@@ -2646,12 +2648,15 @@ void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, 
     else launch_ws_lds<4>(w, rpl2, lds_bytes, s);
   } else {
     // L2-resident G (n > 144): 1024 threads = 64 pair groups halve the passes per step (the kernel is bound by L2 latency there)
-    if (rpl2 == 7 && !getenv("OMC_CONE_512")) hipLaunchKernelGGL((k_cone_ws<16, false, 7, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
+    if (lpp == 64) {      // orders 513 .. 1024: a whole wave per column pair (16 rows per lane), G in global scratch
+      if (rpl2 == 8) hipLaunchKernelGGL((k_cone_ws<64, false, 8, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
+      else hipLaunchKernelGGL((k_cone_ws<64, false, 0, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
+    } else if (rpl2 == 7 && !getenv("OMC_CONE_512")) hipLaunchKernelGGL((k_cone_ws<16, false, 7, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
     else if (rpl2 == 8 && !getenv("OMC_CONE_512")) hipLaunchKernelGGL((k_cone_ws<16, false, 8, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
     else hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->nB), dim3(512), 0, s, *w);
   }
 }
-size_t omc_cone_sub_lds(int np16) { return ((size_t)2 * SUBP * (np16 + 2) + 4 * 256 + 2 * 16 * 17 + 16 + 16 + 32 + 16 + 8) * sizeof(double); }
+size_t omc_cone_sub_lds(int np16) { return ((size_t)(np16 > 512 ? 1 : 2) * SUBP * (np16 + 2) + 4 * 256 + 2 * 16 * 17 + 16 + 16 + 32 + 16 + 8) * sizeof(double); }
 void omc_launch_cone_sub(const OmcWS* w, hipStream_t s) {
   hipLaunchKernelGGL(k_cone_sub<0>, dim3(w->nB), dim3(256), omc_cone_sub_lds(w->np16), s, *w);
 }

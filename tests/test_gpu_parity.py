@@ -974,3 +974,66 @@ def test_warm_start_mixed_batch_through_few_slots_and_argument_checks(have_gpu, 
         eng.stage(gk, "linear", P, load_from=[4] * len(gk))                # beyond the pool
     assert e.value.code == -3
     eng.close()
+
+
+# ---- round 3: BASELINE config 5 (1000 x 1000, k = 2, 30 % observed): orders above 512 and problems that do not fit the LDS ----------
+def test_altmin_global_slab_variant(have_gpu, omc, orc):
+    """alternating_minimization on problems that do not fit the LDS (k_altmin / k_altmin_k on a per-problem global slab): bit-identical
+    to the LDS-resident launch where both run, and equal to the oracle at the BASELINE config 5 size (1000 x 1000, k = 2: 144 KB of
+    state per problem, over the 128 KB launch limit)."""
+    for k, (n, m) in ((1, (30, 40)), (2, (16, 22))):
+        A, mask = orc.make_instance(n, m, k, seed=90 + k, kind="lowrank", n_indices=int(0.5 * n * m))
+        eng = omc.Engine(A, mask, GAMMA, k)
+        U0 = orc.svd_rounding(np.where(mask, A, 0.0), k)
+        x = np.linalg.qr(np.random.default_rng(5).standard_normal((n, 1)))[0][:, 0]
+        dirs = orc.child_directions("linear", k)
+        nodes = [[], [(x, U0 * 0.7, list(dirs[0]))]]
+        a = eng.alternating_minimization([U0, U0], nodes, "linear", max_iters=30)
+        os.environ["OMC_ALTMIN_NOLDS"] = "1"
+        try:
+            b = eng.alternating_minimization([U0, U0], nodes, "linear", max_iters=30)
+        finally:
+            del os.environ["OMC_ALTMIN_NOLDS"]
+        for g, h in zip(a, b):
+            assert g["n_iters"] == h["n_iters"] and np.array_equal(g["objectives"], h["objectives"])
+            assert np.array_equal(g["U"], h["U"]) and np.array_equal(g["V"], h["V"])
+        eng.close()
+    A, mask, gamma, c = omc.pkg.data.config_instance(5, seed=0)
+    n, m = A.shape
+    inst = orc.Instance(A, mask, gamma, 2)
+    eng = omc.Engine(A, mask, gamma, 2)
+    U0 = orc.svd_rounding(np.where(mask, A, 0.0), 2)
+    x = np.linalg.qr(np.random.default_rng(6).standard_normal((n, 1)))[0][:, 0]
+    cuts = [(x, U0 * 0.8, list(orc.child_directions("linear", 2)[0]))]
+    got = eng.alternating_minimization([U0, U0], [[], cuts], "linear", max_iters=4)
+    for g, cl in zip(got, [[], cuts]):
+        r = orc.alternating_minimization(inst, U0, cl, "linear", max_iters=4)
+        assert g["n_iters"] == r["n_iters"] and g["converged"] == r["converged"]
+        assert np.allclose(g["objectives"], r["objectives"], rtol=1e-8)
+        assert np.allclose(g["U"] @ g["V"], r["U"] @ r["V"], atol=1e-5)
+        assert g["master_objective"] == pytest.approx(orc.evaluate_objective(g["U"] @ g["V"], A, mask, gamma), rel=1e-10)
+    eng.close()
+
+
+def test_config5_node_evaluation(have_gpu, omc, orc):
+    """One node of BASELINE config 5 (1000 x 1000, k = 2, 30 % observed, cone order 1002): the L2-resident eigen-kernel with a whole
+    wave per rotation pair seeds the 16-vector block (Z slab in global memory above order 512), which then does the projections.
+    100 iterations (a full solve is minutes): outputs finite, the Lagrangian bound valid against the best
+    known feasible objective (the rounded altmin point), Y inside its cone up to the truncation."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(5, seed=0)
+    n, m = A.shape
+    eng = omc.Engine(A, mask, gamma, 2)
+    P = omc.default_params(rho_scale=4.0, max_iters=100, check_every=25)
+    o = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P, want_X=True)[0]
+    assert_finite(o)
+    assert o["iters"] == 100 and o["status_code"] in (1, 3) and o["feasible"]
+    st = eng.subspace_stats()
+    assert st["calls"] >= 20 and st["fallbacks"] <= 5, st
+    U0 = orc.svd_rounding(np.where(mask, A, 0.0), 2)
+    am = eng.alternating_minimization([U0], [[]], "linear", max_iters=20)[0]
+    ub = am["master_objective"]
+    assert o["dual_bound"] <= ub * (1 + 1e-9)                             # valid lower bound (any feasible rank-2 point is above it)
+    assert o["X"].shape == (n, m) and o["Y"].shape == (n, n)
+    w = np.linalg.eigvalsh(o["Y"])
+    assert w[0] >= -1e-2 and w[-1] <= 1 + 1e-2 and np.trace(o["Y"]) <= 2 + 1e-6
+    eng.close()

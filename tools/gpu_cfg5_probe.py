@@ -9,7 +9,7 @@ os.environ["OMC_GRAPH_MAX"] = "0"
 A, mask, gamma, c = data.config_instance(5, seed=0)
 eng = omc_amd.Engine(A, mask, gamma, c["k"])
 IT = int(os.environ.get("ITERS", "2"))
-P = omc_amd.default_params(rho_scale=4.0, max_iters=IT, breakpoints=2, check_every=int(os.environ.get("CHECK", "1000")))
+P = omc_amd.default_params(rho_scale=4.0, max_iters=IT, breakpoints=2, check_every=int(os.environ.get("CHECK", str(IT))))
 t0 = time.time()
 eng.stage([[]], c["cut_type"], P)
 t1 = time.time(); eng.solve(); t = time.time() - t1
