@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--frontier-file", default=None, help="N=1: cache of the tuned penalty scale and the frontier (written when absent, read when present) so that a "
                     "profiled run launches the kernels of the timed steps only (tools/prof_round2.sh)")
     ap.add_argument("--warm", type=int, default=int(os.environ.get("OMC_BENCH_WARM", 1)), help="1: every node starts from its parent's final state (omc_relax_set_warm), as in a B&B run where "
-                    "a child is relaxed after its parent; 0: cold starts (the reference rebuilds every model, OMC.jl:1482)")
+                    "a child is relaxed after its parent -- the ancestors are relaxed level by level before the timed region, each from its own parent's state; "
+                    "2: only the frontier's parents are relaxed beforehand, cold; 0: cold starts (the reference rebuilds every model, OMC.jl:1482)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip latency_b1 / branching / time_to_gap / cpu_baseline (rank 0, N=1 only)")
     return ap.parse_args()
 
@@ -197,19 +198,29 @@ def main():
                 nxt.extend(bnb.make_children(cuts, o, cfg["cut_type"], k) if o["feasible"] else [cuts])
             mine = nxt
         nodes = mine[:B]
-    # warm start: a node of the frontier is a child of a depth-(d-1) node.  The parents are relaxed once (untimed) and leave their final states
-    # in the device pool -- inputs of the timed region, as the parent's state is an input of a child's relaxation in a B&B run
+    # warm start: a node of the frontier is a child of a depth-(d-1) node, itself the child of a depth-(d-2) node, ...  As in a B&B run, where
+    # every node inherits its parent's final state (omc_relax_set_warm), the ancestors are relaxed level by level (untimed), each from its
+    # own parent's state, and leave their final states in the device pool -- the depth-(d-1) states are inputs of the timed region, as the
+    # parent's state is an input of a child's relaxation in the driver.  --warm 2: the depth-(d-1) parents alone, cold-started (round-3 first form)
     load_from = None; n_parents = 0
     if args.warm:
-        pkey = {}; parents = []; load_from = []
+        pidx = {(): 0}; levels = [[((), [])]]                  # prefix key (ids of the cut objects) -> pool index ; per depth: (key, cut list)
         for cuts in nodes:
-            key = tuple(id(c) for c in cuts[:-1]) if len(cuts) else None
-            if key not in pkey:
-                pkey[key] = len(parents); parents.append(list(cuts[:-1]))
-            load_from.append(pkey[key])
-        n_parents = len(parents)
-        eng.state_pool_create(n_parents)
-        eng.matrix_completion_SDP_relaxation(parents, cfg["cut_type"], params=P, want_Y=False, want_X=False, save_to=list(range(n_parents)))
+            for l in range(1, len(cuts)):
+                key = tuple(id(c) for c in cuts[:l])
+                if key not in pidx:
+                    pidx[key] = len(pidx)
+                    while len(levels) <= l:
+                        levels.append([])
+                    levels[l].append((key, list(cuts[:l])))
+        load_from = [pidx[tuple(id(c) for c in cuts[:-1])] if len(cuts) else -1 for cuts in nodes]
+        n_parents = len(levels[-1])
+        eng.state_pool_create(len(pidx))
+        for l, lev in enumerate(levels):
+            if args.warm == 2 and l + 1 < len(levels):
+                continue
+            lf = [-1 if (l == 0 or args.warm == 2) else pidx[key[:-1]] for key, _ in lev]
+            eng.matrix_completion_SDP_relaxation([c for _, c in lev], cfg["cut_type"], params=P, want_Y=False, want_X=False, load_from=lf, save_to=[pidx[key] for key, _ in lev])
     eng.stage(nodes, cfg["cut_type"], P, load_from=load_from)           # node descriptors (and parent states) resident in HBM before the timed region
 
     def step():
@@ -228,7 +239,8 @@ def main():
     # slots, whose kernels events cannot see) is switched off for them, so that the per-kernel averages below and rocprofv3's describe the
     # same launches; the extras (latency_b1, branching) run with the library default
     graph_env = os.environ.get("OMC_GRAPH_MAX")
-    os.environ["OMC_GRAPH_MAX"] = "0"
+    if os.environ.get("OMC_TIMING_STRIDE", "1") == "1":
+        os.environ["OMC_GRAPH_MAX"] = "0"
     for _ in range(args.warmup):
         step()
     kstats = {}; sub = {}
@@ -270,7 +282,7 @@ def main():
     cone_ms = kstats["cone"]["ms"] + kstats["cone_sub"]["ms"]
     projections = kstats["global"]["units"]                      # one projection per node-iteration
     launches = max(1, kstats["global"]["launches"])
-    achieved = f_proj(n) * projections / (cone_ms * 1e-3) / 1e12
+    achieved = f_proj(n) * projections / (max(cone_ms, 1e-9) * 1e-3) / 1e12          # cone_ms = 0 only with OMC_TIMING_STRIDE=0 (no event timing: experiments)
     np16 = (n + 15) // 16 * 16
     executed_sub = (sub.get("power_steps", 0) + sub.get("ritz_passes", 0)) * 2.0 * np16 * np16 * 16     # MFMA flops of the M X products of k_cone_sub
     traffic = None; peak_measured = None

@@ -14,6 +14,8 @@ A node is the reference's BBNode reduced to what the relaxation reads: a list of
 """
 from __future__ import annotations
 
+import atexit
+import weakref
 import ctypes as C
 
 import numpy as np
@@ -89,6 +91,20 @@ def shor_rank_k_extension(k, X, W, minors):
     return dict(Xt=Xt, Wt=Wt, H=H, V=V)
 
 
+_LIVE = weakref.WeakSet()      # engines still holding a device instance: closed before the interpreter (and then the HIP runtime) goes down
+
+
+def _close_all():
+    for e in list(_LIVE):
+        try:
+            e.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
+
+
 class Engine:
     """Device-resident instance + the four call sites of the reference driver."""
 
@@ -104,8 +120,10 @@ class Engine:
         mask = np.asfortranarray(self.indices.astype(np.uint8))
         _lib.check(self._lib.omc_instance_create(self.n, self.m, self.k, _lib.ptr(self.A), _lib.ptr(mask), self.gamma,
                                                  int(device), C.byref(self._h)))
+        _LIVE.add(self)
 
     def close(self):
+        _LIVE.discard(self)
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.omc_instance_destroy(self._h)
             self._h = C.c_void_p()

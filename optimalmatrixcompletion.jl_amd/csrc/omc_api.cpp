@@ -66,10 +66,11 @@ struct omc_instance {
   DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arbj, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG, aG2;
   hipStream_t stream = nullptr;
   // per slot group: main / column / small-cone streams and fork, join, done events (see omc_relax_solve)
-  hipStream_t gs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  hipEvent_t gev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  hipStream_t gs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  hipEvent_t gev[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t ev_main = nullptr;
-  DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY;
+  DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY, dsolo;
+  int nsolo = 0;      // columns that k_colprox_pair leaves to k_colprox (more than 32 observed rows, unpaired last column)
   // batch workspace
   DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
@@ -186,6 +187,17 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   if ((rc = upload(h->dA, h->A.data(), sizeof(double) * n * m, h->stream))) return rc;
   if ((rc = upload(h->dmask, h->mask.data(), (size_t)n * m, h->stream))) return rc;
   if ((rc = upload(h->dcol_ptr, h->col_ptr.data(), sizeof(int) * (m + 1), h->stream))) return rc;
+  {
+    std::vector<int> solo;
+    for (int j0 = 0; j0 < m; j0 += 2) {
+      const int j1 = j0 + 1;
+      const int c0 = h->col_ptr[j0 + 1] - h->col_ptr[j0], c1 = (j1 < m) ? h->col_ptr[j1 + 1] - h->col_ptr[j1] : 0;
+      if (j1 < m && c0 <= 32 && c1 <= 32) continue;
+      solo.push_back(j0); if (j1 < m) solo.push_back(j1);
+    }
+    h->nsolo = (int)solo.size();
+    if (h->nsolo && (rc = upload(h->dsolo, solo.data(), sizeof(int) * solo.size(), h->stream))) return rc;
+  }
   if ((rc = upload(h->dcol_idx, h->col_idx.data(), sizeof(int) * h->nnz, h->stream))) return rc;
   if ((rc = upload(h->dcol_val, h->col_val.data(), sizeof(double) * h->nnz, h->stream))) return rc;
   if ((rc = upload(h->dNcnt, h->Ncnt.data(), sizeof(double) * n * n, h->stream))) return rc;
@@ -214,7 +226,7 @@ void omc_instance_destroy(omc_instance* h) {
   (void)hipSetDevice(h->device);
   (void)omc_comm_destroy(h);
   h->bcomm.release(); h->amobj.release();
-  DevBuf* all[] = {&h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
+  DevBuf* all[] = {&h->dsolo, &h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
@@ -230,8 +242,8 @@ void omc_instance_destroy(omc_instance* h) {
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (int g = 0; g < 2; ++g) {
-    for (int q = 0; q < 3; ++q) if (h->gs[g][q]) (void)hipStreamDestroy(h->gs[g][q]);
-    for (int q = 0; q < 4; ++q) if (h->gev[g][q]) (void)hipEventDestroy(h->gev[g][q]);
+    for (int q = 0; q < 4; ++q) if (h->gs[g][q]) (void)hipStreamDestroy(h->gs[g][q]);
+    for (int q = 0; q < 5; ++q) if (h->gev[g][q]) (void)hipEventDestroy(h->gev[g][q]);
   }
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   delete h;
@@ -446,6 +458,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   int rc_ = 0;
   if ((rc_ = upload(h->dwY, wY.data(), sizeof(double) * n * n, h->stream))) return rc_;
   w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
+  w.cp_pair = getenv("OMC_NO_COLPROX_PAIR") ? 0 : 1; w.cp_nsolo = h->nsolo; w.cp_solo = h->nsolo ? h->dsolo.as<int>() : nullptr;
   w.Ncnt = h->dNcnt.as<double>(); w.wY1 = h->dwY.as<double>();
   w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>();
 #define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)
@@ -472,13 +485,15 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   }
   w.Mbuf = h->bMbuf.as<double>(); w.Vrow = h->bVrow.as<double>();
   {   // tracked subspace of the cone block (k_cone_sub)
-    ENS(h->bXs, sB * w.np16 * 16 * 8); ENS(h->bsubS, sB * (17 + 256) * 8); ENS(h->bsubI, sB * 13 * sizeof(int));
+    ENS(h->bXs, sB * w.np16 * 16 * 8); ENS(h->bsubS, sB * (17 + 256) * 8); ENS(h->bsubI, sB * 14 * sizeof(int));
     HIPCHK(hipMemsetAsync(h->bXs.p, 0, sB * w.np16 * 16 * 8, h->stream));
     HIPCHK(hipMemsetAsync(h->bsubS.p, 0, sB * (17 + 256) * 8, h->stream));
-    HIPCHK(hipMemsetAsync(h->bsubI.p, 0, sB * 13 * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->bsubI.p, 0, sB * 14 * sizeof(int), h->stream));
     w.Xs = h->bXs.as<double>(); w.sub_theta = h->bsubS.as<double>(); w.trM = h->bsubS.as<double>() + sB * 16;
     w.sub_on = h->bsubI.as<int>(); w.cone_done = h->bsubI.as<int>() + sB; w.sub_stat = h->bsubI.as<int>() + 2 * sB; w.sub_wait = h->bsubI.as<int>() + 10 * sB; w.sub_nfail = h->bsubI.as<int>() + 11 * sB;
     w.V3 = getenv("OMC_SMALL_COLD") ? nullptr : h->bsubS.as<double>() + sB * 17; w.v3valid = h->bsubI.as<int>() + 12 * sB;
+    w.ws_first = h->bsubI.as<int>() + 13 * sB; w.ws_phase = 0;
+    w.sub_guard = getenv("OMC_SUB_GUARD") ? atoi(getenv("OMC_SUB_GUARD")) : 2;
     w.sub_qmax = getenv("OMC_SUB_QMAX") ? atoi(getenv("OMC_SUB_QMAX")) : 24;
     w.sub_chunk = getenv("OMC_SUB_CHUNK") ? atoi(getenv("OMC_SUB_CHUNK")) : 3;
     w.sub_lazy = getenv("OMC_SUB_LAZY") ? atoi(getenv("OMC_SUB_LAZY")) : 1;
@@ -746,8 +761,8 @@ int omc_relax_solve(omc_instance* h) {
   const int G = (multi && S >= 64 && getenv("OMC_GROUPS") && atoi(getenv("OMC_GROUPS")) == 2) ? 2 : 1;
   if (multi && !h->ev_main) {
     for (int g = 0; g < 2; ++g) {
-      for (int q = 0; q < 3; ++q) HIPCHK(hipStreamCreateWithFlags(&h->gs[g][q], hipStreamNonBlocking));
-      for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreateWithFlags(&h->gev[g][q], hipEventDisableTiming));
+      for (int q = 0; q < 4; ++q) HIPCHK(hipStreamCreateWithFlags(&h->gs[g][q], hipStreamNonBlocking));
+      for (int q = 0; q < 5; ++q) HIPCHK(hipEventCreateWithFlags(&h->gev[g][q], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
   }
@@ -778,6 +793,7 @@ int omc_relax_solve(omc_instance* h) {
   // large batches that the bench times keep the eager path.
   const int graph_max = getenv("OMC_GRAPH_MAX") ? atoi(getenv("OMC_GRAPH_MAX")) : 16;      // measured: -6 % per iteration at batch 1, +8 % at 128 slots of order 200
   const bool no_graph = getenv("OMC_NO_GRAPH") != nullptr;      // read once per solve, not per iteration
+  const int timing_stride = getenv("OMC_TIMING_STRIDE") ? atoi(getenv("OMC_TIMING_STRIDE")) : 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr}; int gexec_n = -1;
   struct GraphGuard { hipGraphExec_t* e; ~GraphGuard() { for (int q = 0; q < 2; ++q) if (e[q]) (void)hipGraphExecDestroy(e[q]); } } gguard{gexec};
   auto body = [&](int g, const OmcWS& wg, bool timed, bool with_aa) -> int {
@@ -811,12 +827,28 @@ int omc_relax_solve(omc_instance* h) {
       MAYBE_TIMED(sm, OMC_KERNEL_SHOR_MINORS, gact[g], { omc_shor_launch_minor_post(&sw, sm); omc_shor_launch_reduce(&sw, sm); });
       return 0;
     }
+    // The full eigen-kernel runs the slots that have no tracked block (or are backing off) -- a handful per launch, each a long single-workgroup
+    // job, known before the iteration starts (ws_first) -- on a stream of its own beside k_cone_sub; what k_cone_sub then could not do (a failed
+    // call, ~1 in 30 000) is a second, almost empty launch behind both.  One launch after k_cone_sub made every iteration wait for the sum.
+    static const bool ws_split_ok = getenv("OMC_NO_WS_SPLIT") == nullptr;
+    const bool split = multi && ws_split_ok && w.sub_enable && h->ws_lpp && w.ws_first;
+    if (split) {      // on the small-cone stream, behind k_small (a fifth stream would share a hardware queue with one of the other four: measured, k_small then ran behind it)
+      MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
+      OmcWS wA = wg; wA.ws_phase = 1;
+      MAYBE_TIMED(sc, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wA, h->ws_lpp, h->ws_use_lds, h->ws_lds, sc));
+      HIPCHK(hipEventRecord(h->gev[g][4], sc));
+    }
     if (colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
     if (w.sub_enable) MAYBE_TIMED(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
     if (!colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
-    if (h->ws_lpp) MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
+    if (split) {
+      HIPCHK(hipStreamWaitEvent(sm, h->gev[g][4], 0));
+      OmcWS wB = wg; wB.ws_phase = 2;
+      MAYBE_TIMED(sm, OMC_KERNEL_CONE, 0, omc_launch_cone_ws(&wB, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
+    }
+    else if (h->ws_lpp) MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wg, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
     else MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone(&wg, CONE_CLIP01, h->cone_use_lds, h->cone_lds, sm));
-    MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
+    if (!split) MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
     if (multi) {
       HIPCHK(hipEventRecord(h->gev[g][1], sb)); HIPCHK(hipEventRecord(h->gev[g][2], sc));
       HIPCHK(hipStreamWaitEvent(sm, h->gev[g][1], 0)); HIPCHK(hipStreamWaitEvent(sm, h->gev[g][2], 0));
@@ -829,7 +861,10 @@ int omc_relax_solve(omc_instance* h) {
     ++it;
     const bool is_check = (it % check == 0);
     if (multi && wait_main) HIPCHK(hipEventRecord(h->ev_main, s));
-    const bool use_graph = multi && G == 1 && use_list && nlist <= graph_max && !no_graph;
+    // per-kernel HIP-event timing brackets every launch of a sampled iteration (two event records per kernel: ~25 us of queue bubbles per
+    // iteration at small batches); OMC_TIMING_STRIDE=s samples every s-th iteration (averages per launch are over the sampled launches), 0 = none
+    const bool sampled = timing_stride > 0 && (it % timing_stride) == 0;
+    const bool use_graph = multi && G == 1 && use_list && nlist <= graph_max && !no_graph && !(sampled && timing_stride > 1);
     for (int g = 0; g < G; ++g) {
       if (gact[g] == 0) continue;
       OmcWS wg = w; wg.b0 = gb0[g]; wg.nB = gnB[g];
@@ -856,7 +891,7 @@ int omc_relax_solve(omc_instance* h) {
         HIPCHK(hipGraphLaunch(gexec[q], sm));
         h->launches[OMC_KERNEL_GLOBAL] += 1; h->units[OMC_KERNEL_GLOBAL] += gact[g];
       } else {
-        int rc = body(g, wg, true, !is_check && w.accel); if (rc) return rc;
+        int rc = body(g, wg, sampled, !is_check && w.accel); if (rc) return rc;
       }
       if (multi && is_check) { HIPCHK(hipEventRecord(h->gev[g][3], sm)); HIPCHK(hipStreamWaitEvent(s, h->gev[g][3], 0)); }
     }
@@ -1316,7 +1351,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   OmcWS& wb = h->wbig;
   wb = w;
   wb.n = N; wb.np16 = NPb; wb.Mbuf = sh.MbufB; wb.Vrow = sh.VrowB; wb.vvalid = sh.vvalidB; wb.fro2 = sh.fro2B; wb.W1 = sh.P0;
-  wb.sub_enable = 0; wb.cert_enable = 0; wb.ws_mode = 0; wb.clip_hi = 1e300; wb.sub_debug = 0;
+  wb.sub_enable = 0; wb.cert_enable = 0; wb.ws_mode = 0; wb.clip_hi = 1e300; wb.sub_debug = 0; wb.ws_first = nullptr; wb.ws_phase = 0;
   {
     const int Np2 = (N + 1) & ~1;
     int lpp = 16; while (lpp > 4 && lpp * (Np2 / 2) > 512) lpp >>= 1;
@@ -1357,7 +1392,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
     wb.sub_enable = 1; wb.Xs = h->sXsB.as<double>(); wb.sub_theta = h->ssubSB.as<double>();
     wb.sub_zscratch = nullptr;
     if (NPb > 512) { ENS(h->bsubz, sB * 16 * (size_t)(NPb + 2) * 8); wb.sub_zscratch = h->bsubz.as<double>(); }
-    wb.sub_on = sh.sub_onB; wb.cone_done = sh.cone_doneB; wb.sub_wait = sh.sub_waitB; wb.sub_nfail = sh.sub_nfailB; wb.sub_stat = si + 4 * sB;
+    wb.ws_first = nullptr; wb.ws_phase = 0; wb.sub_on = sh.sub_onB; wb.cone_done = sh.cone_doneB; wb.sub_wait = sh.sub_waitB; wb.sub_nfail = sh.sub_nfailB; wb.sub_stat = si + 4 * sB;
     wb.sep_done = nullptr;
   }
   HIPCHK(hipStreamSynchronize(s));

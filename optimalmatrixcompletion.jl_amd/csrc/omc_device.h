@@ -83,6 +83,11 @@ struct OmcWS {
   double* V3; int* v3valid;  // B * 256, B: eigenvectors of the last small-cone projection (order <= 16), warm start of the next one (NULL: cold every time)
   int *sub_wait, *sub_nfail; // B: iterations left before the subspace is tried again after a failure ; failures so far (back-off)
   int *sub_on, *cone_done;   // B: slot follows the subspace ; this iteration's W1 has been written by k_cone_sub
+  // the slots the full kernel must project this iteration are known before it starts (no block yet, or backing off): ws_first[b], written by
+  // k_setup / k_global.  ws_phase 1 = those slots only (runs beside k_cone_sub on its own stream), 2 = what k_cone_sub then left (a failed
+  // call: ~1 in 30 000), 0 = both in one launch after k_cone_sub (ws_first NULL: the Shor-mode views)
+  int* ws_first; int ws_phase;
+  int sub_guard;             // Ritz values of the tracked block that must stay negative (the block holds at most 16 - sub_guard positive ones)
   // certificate estimator (k_cone_sub<1>): block of the most negative eigenvectors of Mchk, its Ritz values (of -Mchk), trace of MbufC
   int* sep_done;          // B: the separation vector of this harvested slot came from the tracked block (k_cone_sub<2>); NULL = feature off
   int cert_enable; double *XsC, *sub_thetaC, *trMc, *lb_est; int *sub_onC, *confirm;
@@ -112,6 +117,9 @@ struct OmcWS {
   // scratch
   double* cp_scratch;  size_t cp_scratch_stride;   // per wave (B*m waves) when a column is too large for LDS
   int cp_lds_c; int cp_lds_doubles; int cp_keepB;   // cp_keepB = 0: dense columns, B is gathered again instead of kept in LDS
+  // k_colprox_pair: two columns per wave (32 lanes each, matrix rows in registers) for the column pairs (2p, 2p + 1) whose columns hold at
+  // most 32 observed rows each; the other columns (cp_solo, cp_nsolo of them) keep the one-column-per-wave kernel
+  int cp_pair; int cp_nsolo; const int* cp_solo;
   double* cone_scratch; size_t cone_scratch_stride; // per node when N is too large for LDS
   double* glob_scratch; size_t glob_scratch_stride;
   double* small_scratch; size_t small_scratch_stride;

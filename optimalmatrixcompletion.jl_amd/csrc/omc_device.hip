@@ -13,6 +13,7 @@
 // plus k_check* (certificate: exact f(Y), Lagrangian dual bound) every `check_every` iterations.
 // Wavefront = 64 everywhere.  No CUDA compatibility paths.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include "omc_device.h"
 
@@ -98,7 +99,7 @@ __global__ void k_setup(OmcWS w) {
     if (tid < 16) w.sub_theta[(size_t)b * 16 + tid] = w.ptheta[(size_t)lf * 16 + tid];
     fr2 = block_sum(fr2, red); tr1 = block_sum(tr1, red);
     if (tid == 0) {
-      w.fro2[b] = fr2; w.trM[b] = tr1; w.sub_on[b] = (w.sub_enable && w.pscal[(size_t)lf * 4 + 1] != 0.0) ? 1 : 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.v3valid[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
+      w.fro2[b] = fr2; w.trM[b] = tr1; w.sub_on[b] = (w.sub_enable && w.pscal[(size_t)lf * 4 + 1] != 0.0) ? 1 : 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.v3valid[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0; if (w.ws_first) w.ws_first[b] = w.sub_on[b] ? 0 : 1;
     }
     // Vt = Q_child' U_parent, U = Q_child Vt
     for (int e = tid; e < rm * k; e += T) {
@@ -132,7 +133,7 @@ __global__ void k_setup(OmcWS w) {
       w.Vrow[(size_t)b * NP * NP + e] = 0.0;
     }
     if (tid == 0) {
-      w.fro2[b] = d0 * d0 * n; w.trM[b] = d0 * n; w.sub_on[b] = 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.v3valid[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0;
+      w.fro2[b] = d0 * d0 * n; w.trM[b] = d0 * n; w.sub_on[b] = 0; w.sub_wait[b] = 0; w.sub_nfail[b] = 0; w.cone_done[b] = 0; w.v3valid[b] = 0; w.sub_onC[b] = 0; w.confirm[b] = 1; w.lb_est[b] = -1e300; w.vvalid[b] = 0; if (w.vvalidC) w.vvalidC[b] = 0; if (w.ws_first) w.ws_first[b] = w.sub_on[b] ? 0 : 1;
     }
   }
   for (int e = tid; e < n * k; e += T) w.U[(size_t)b * n * k + e] = 0.0;
@@ -466,12 +467,223 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_colprox_pair: the column prox (mode 0 of k_colprox) with TWO columns per wave.  A column of config 2 has ~20 observed rows: with one
+// column per wave 20 of 64 lanes worked, and the factorisation spent most of its instructions on v_readlane broadcasts (SGPR round trips).
+// Here each half-wave (32 lanes) owns one column, lane l of a half owns matrix row l, and the whole row lives in REGISTERS:
+//   R[q], q < l   strictly lower part (A = B + cp s I on entry, the unit-lower factor L on exit; zero on and above the diagonal),
+//   dg            the diagonal entry (the pivot d_l on exit).
+// Right-looking L D L': at step k every lane stages its entry of column k in LDS (one ds_write), and reads pivot and the column entries of the
+// other rows back as half-uniform (broadcast) ds_reads -- no cross-lane VALU traffic in the O(c^2) part, one fma per (row, k, q).
+// Forward substitution: one half-wave broadcast per step (DPP row_newbcast + v_permlane16_swap, no SGPR); backward substitution in
+// inner-product form: one half-wave sum per step (DPP adds + v_permlane16_swap).  B stays in registers for the second factorisation.
+// The secular iteration of colprox_reg is carried per half (all of its scalars are half-uniform lane values); a half that has finished
+// idles while the other one goes on.  Columns with more than 32 rows and unpaired last columns stay with k_colprox (w.cp_solo).
+// ---------------------------------------------------------------------------------------------------------
+template <int Q>
+__device__ __forceinline__ double half_bcast(double v) {      // value of lane Q (0..31) of each half-wave, in every lane of that half
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + (Q & 15), 0xF, 0xF, false);      // row_newbcast: lane Q & 15 of every row of 16
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + (Q & 15), 0xF, 0xF, false);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);                  // [0]: even rows copied into the odd ones, [1]: the reverse
+  auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return (Q < 16) ? __hiloint2double(c[0], a[0]) : __hiloint2double(c[1], a[1]);
+}
+__device__ __forceinline__ double half_sum(double v) {        // sum over the 32 lanes of each half-wave, in every lane of that half
+  v = group_sum_dpp<16>(v);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(c[0], a[0]) + __hiloint2double(c[1], a[1]);
+}
+#define CPP_C 32
+template <int Q, int QEND, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (Q < QEND) { f(std::integral_constant<int, Q>{}); static_for<Q + 1, QEND>(f); }
+}
+#define CPP_LDS_DOUBLES (64 + 64 + 32)      // per wave: staged column, previous alpha, row indices (64 ints)
+
+__global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
+  extern __shared__ double smem[];
+  const int wave_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, wpb = blockDim.x >> 6;      // scalar: every guard below is a wave-uniform branch
+  const int gw = blockIdx.x * wpb + wave_in_blk;
+  const int mp = (w.m + 1) >> 1;
+  const int bl = gw / mp, pr = gw - bl * mp;
+  if (bl >= w.nB) return;
+  const int b = slot_of(w, bl);
+  if (w.done[b]) return;
+  const int j0 = 2 * pr, j1 = j0 + 1;
+  const int off0 = w.col_ptr[j0], c0 = w.col_ptr[j0 + 1] - off0;
+  const int off1 = (j1 < w.m) ? w.col_ptr[j1] : 0, c1 = (j1 < w.m) ? w.col_ptr[j1 + 1] - off1 : 0;
+  if (c0 > CPP_C || c1 > CPP_C || j1 >= w.m) return;           // k_colprox runs these columns (w.cp_solo)
+  const int cmax = __builtin_amdgcn_readfirstlane((c0 > c1) ? c0 : c1);      // wave-uniform, in an SGPR
+  if (cmax == 0) return;
+  double* st = smem + (size_t)wave_in_blk * CPP_LDS_DOUBLES;    // 64: staged column
+  double* vo_s = st + 64;                                       // 64: alpha of the previous iteration
+  int* sidx = (int*)(vo_s + 64);                                // 64: row indices
+  const int h = lane >> 5, l = lane & 31, hb = h << 5;
+  const int j = j0 + h, off = h ? off1 : off0, c = h ? c1 : c0;
+  const bool act = l < c;
+  const int n = w.n;
+  const double gm = w.gamma;
+  const double* Y = w.Y + (size_t)b * n * n;
+  const double* Yp = w.Yp + (size_t)b * n * n;
+  double* alpha = w.alpha + (size_t)b * w.nnz + off;
+  const double a_reg = act ? w.col_val[off + l] : 0.0;
+  const int my = act ? w.col_idx[off + l] : 0;
+  const double vo_r = act ? alpha[l] : 0.0;
+  sidx[lane] = my; vo_s[lane] = vo_r;
+  const double rho_f = w.rho_b[b] * w.rho_f_ratio;
+  const double coef = gm / (2.0 * rho_f), cp = gm * gm / (2.0 * rho_f);
+  // ---- B = I + gamma ((2 Y - Yp)[O, O] - coef a_old a_old'): row l of the strictly lower triangle in registers, every load issued before its use
+  double Bq[CPP_C], Bd;
+  {
+    const size_t ad = (size_t)my * n + my;
+    const double yd = 2.0 * Y[ad] - Yp[ad];
+    Bd = act ? fma(gm, yd - coef * vo_r * vo_r, 1.0) : 1.0;
+#pragma unroll
+    for (int qb = 0; qb < CPP_C; qb += 8) {
+      if (qb < cmax) {
+        double y1[8], y2[8], vq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int iq = sidx[hb + qb + u];
+          vq[u] = vo_s[hb + qb + u];
+          const size_t a = (size_t)iq * n + my;
+          y1[u] = Y[a]; y2[u] = Yp[a];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double v = gm * ((2.0 * y1[u] - y2[u]) - coef * vo_r * vq[u]);
+          Bq[qb + u] = (act && l > qb + u) ? v : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Bq[qb + u] = 0.0;
+      }
+    }
+  }
+  double R[CPP_C], dg, dinv;
+  // L D L' of B + shift I, both halves at once; returns (per half) whether every pivot was positive
+  auto factor = [&](double shift) -> bool {
+#pragma unroll
+    for (int q = 0; q < CPP_C; ++q) R[q] = Bq[q];
+    dg = Bd + shift;
+    bool good = true;
+    int cm = cmax;
+    asm volatile("" : "+s"(cm));      // same for the wave-uniform guards (k < cmax): s_cmp + s_cbranch_scc where they stand
+    int lv = l;
+    asm volatile("" : "+v"(lv));      // opaque copy: the 64 lane masks (l == k, l > k) are compared where they are used -- hoisted out of the secular loop they were spilled to VGPR lanes (v_writelane / v_readlane + s_nop per use)
+#pragma unroll
+    for (int k = 0; k < CPP_C; ++k) {
+      if (k < cm) {                                              // wave-uniform
+        st[lane] = (lv == k) ? dg : R[k];
+        const double d = st[hb + k];
+        good = good && (d > 1e-290);
+        const double pinv = fast_rcp(d);
+        const double lk = (lv > k) ? R[k] * pinv : 0.0;         // unit-lower entry L(l, k); zero on and above the diagonal
+        dg = fma(-lk, R[k], dg);
+#pragma unroll
+        for (int qb = 0; qb < CPP_C; qb += 4) {
+          if (qb + 3 > k && qb < cm) {                         // wave-uniform; rows beyond a column's size hold zeros
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int q = qb + u;
+              if (q > k) R[q] = fma(-lk, st[hb + q], R[q]);
+            }
+          }
+        }
+        R[k] = lk;
+      }
+    }
+    dinv = fast_rcp(dg);
+    return good;
+  };
+  // x = (L D L')^-1 rhs, vector in registers (lane = entry)
+  auto solve = [&](double rhs) -> double {
+    int cm = cmax;
+    asm volatile("" : "+s"(cm));
+    double f = rhs;
+    static_for<0, CPP_C - 1>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if (q + 1 < cm) f = fma(-R[q], half_bcast<q>(f), f);     // R[q] = 0 in lanes l <= q
+    });
+    double x = f * dinv;
+    int lv = l;
+    asm volatile("" : "+v"(lv));
+    static_for<0, CPP_C - 1>([&](auto ic) {
+      constexpr int q = CPP_C - 2 - decltype(ic)::value;
+      if (q + 1 < cm) {
+        const double sm_ = half_sum(R[q] * x);                   // sum over l > q of L(l, q) x_l
+        x = (lv == q) ? x - sm_ : x;
+      }
+    });
+    return x;
+  };
+  // ---- secular equation || (B + cp s I)^-1 a ||^2 = s: Halley steps with the Taylor finish of colprox_reg, per half.  ONE instance of the
+  // factorisation and ONE of the solve in the instruction stream (the inlined code of both is ~2.5 k instructions): the solves of a pass
+  // (y, z = A^-1 y and, for the Taylor finish, w = A^-1 z) run through a loop, and the closing factorisation of a column that has used up
+  // its 60 steps is pass 60 of the same loop
+  const double sprev = (j < w.m) ? w.sval[(size_t)b * w.m + j] : 0.0;
+  double s = (sprev > 0.0) ? sprev : 0.0;
+  double lo = 0.0, hi = -1.0;
+  bool lo_valid = false, fin = (c == 0);
+  double yout = 0.0;
+  for (int it = 0; it <= 60; ++it) {
+    if (!__any(!fin)) break;
+    const bool last = (it == 60);
+    const bool ok_ = factor(cp * s);
+    double yr = 0.0, zr = 0.0, rhs = a_reg;
+    bool want_w = false; double dstep = 0.0, snext = s;
+    for (int sv = 0; sv < 3; ++sv) {
+      const double x = solve(rhs);
+      rhs = x;
+      if (sv == 0) {
+        yr = x;
+        if (last) { if (!fin) { yout = yr; fin = true; } break; }
+      } else if (sv == 1) {
+        zr = x;
+        const double yy = half_sum(yr * yr), yz = half_sum(yr * zr), zz = half_sum(zr * zr);
+        if (!fin) {
+          if (!ok_) {                                              // s below the positive definite range: move right
+            lo = s; lo_valid = false;
+            s = (hi > 0.0) ? 0.5 * (s + hi) : (2.0 * s + 1.0);
+          } else {
+            const double ph = yy - s, dph = -2.0 * cp * yz - 1.0, ddph = 6.0 * cp * cp * zz;
+            if (ph >= 0.0) { lo = s; lo_valid = true; } else { hi = s; }
+            const double den = 2.0 * dph * dph - ph * ddph;
+            double sn = s + ((den > dph * dph) ? (-2.0 * ph * dph / den) : (-ph / dph));
+            bool guarded = false;
+            if (!(sn > lo) && !lo_valid) { sn = 0.5 * (lo + s); guarded = true; }
+            if (sn < lo) { sn = lo; guarded = true; }
+            if (hi > 0.0 && sn > hi) { sn = 0.5 * (lo + hi); guarded = true; }
+            const double d = sn - s;
+            if (fabs(d) <= 1e-13 * fmax(1.0, fabs(s))) { fin = true; yout = yr; }      // the current solve is the answer
+            else if (!guarded && yy > 0.0 && cp * fabs(d) * sqrt(zz / yy) < 1e-5) { want_w = true; dstep = d; snext = sn; }
+            else s = sn;
+          }
+        }
+        if (!__any(want_w)) break;
+      } else if (want_w) {                                         // alpha(s + d) = y - cp d z + cp^2 d^2 w, w = A^-1 z
+        yout = yr - cp * dstep * (zr - cp * dstep * x); s = snext; fin = true;
+      }
+    }
+  }
+  if (act) {
+    alpha[l] = yout;
+    w.lamD[((size_t)b * w.m + j) * n + my] = yout;               // dense copy (zeros off the support) for the output-stationary Lambda Lambda'
+    if (l == 0) w.sval[(size_t)b * w.m + j] = s;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_colprox(OmcWS w, int mode) {
   extern __shared__ double smem[];
   const int wave_in_blk = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const int gw = blockIdx.x * wpb + wave_in_blk;  // global wave id
-  const int bl = gw / w.m, j = gw - bl * w.m;
+  const int ncol = (mode == 0 && w.cp_pair) ? w.cp_nsolo : w.m;      // mode 0 with k_colprox_pair: the columns it leaves (more than 32 rows, unpaired last column)
+  const int bl = gw / ncol, jj = gw - bl * ncol;
   if (bl >= w.nB) return;
+  const int j = (mode == 0 && w.cp_pair) ? w.cp_solo[jj] : jj;
   const int b = slot_of(w, bl);
   if (w.done[b]) return;
   const int off = w.col_ptr[j], c = w.col_ptr[j + 1] - off;
@@ -928,7 +1140,7 @@ __global__ void __launch_bounds__(512) k_cone(OmcWS w, int mode) {
 // ---------------------------------------------------------------------------------------------------------
 typedef double double4v __attribute__((ext_vector_type(4)));
 #define SUBP 16   // tracked subspace dimension of k_cone_sub
-#define SUBG 4    // Ritz values that must stay negative (guards)
+#define SUBG 2    // default of w.sub_guard: Ritz values that must stay negative (4 until round 3: nodes whose Y - D1 keeps 13-14 positive eigenvalues -- ~1 % of the slot-iterations at depth 11 -- then sent EVERY launch through the full kernel)
 
 template <int LPP, bool USE_LDS, int RPL2, int TPB = 512>   // RPL2 = rows per lane / 2 as a compile-time constant (0: run-time bound)
 __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
@@ -937,7 +1149,10 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   __shared__ double s_base;
   const int b = slot_of(w, blockIdx.x), tid = threadIdx.x, T = blockDim.x;
   if (w.done[b]) return;
-  if (!w.ws_mode && w.sub_enable && w.cone_done[b]) return;      // k_cone_sub has already written W1 for this iteration
+  if (!w.ws_mode && w.sub_enable) {
+    if (w.ws_phase == 1) { if (!w.ws_first[b]) return; }          // the slots known to need the full kernel, beside k_cone_sub
+    else if (w.cone_done[b]) return;                              // k_cone_sub (or phase 1) has already written W1 for this iteration
+  }
   if (w.ws_mode && w.cert_enable && !w.confirm[b]) return;       // the estimate of k_cone_sub<1> is enough for this check
   const int n = w.n, N = n, NP = w.np16;
   const int Np = (N + 1) & ~1;
@@ -1166,7 +1381,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   __syncthreads();
   // seed the tracked subspace (k_cone_sub) with the SUBP dominant eigenvectors when few eigenvalues are positive
   if (w.sub_enable) {
-    const bool seed = s_nkeep <= SUBP - SUBG && N >= 3 * SUBP;
+    const bool seed = s_nkeep <= SUBP - w.sub_guard && N >= 3 * SUBP;
     if (w.sub_debug == 3 && tid == 0) atomicAdd(&w.stamps[(s_nkeep < 31) ? s_nkeep : 31], 1.0);      // diagnostics: positive eigenvalues seen by the full kernel
     if (seed) {
       // the SUBP largest eigenvalues by rank (ties: the smaller index first), one thread per eigenvalue -- the serial selection this
@@ -1195,7 +1410,7 @@ __global__ void __launch_bounds__(TPB) k_cone_ws(OmcWS w) {
   STAMP(3);
   spectral_rebuild(Gm, ld, N, sel, wgt, s_nsel, s_base, entry2, store);
   STAMP(4);
-  if (tid == 0) { DIAG_CYC(2, b); DIAG_ADD(3, b, 1); }
+  if (tid == 0) { DIAG_CYC(2, b); DIAG_ADD(3, b, 1); if (w.ws_phase == 1) w.cone_done[b] = 1; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1228,8 +1443,12 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
   } else {
     if (w.done[b]) return;
     if (MODE == 0) {
-      if (!w.sub_on[b]) return;
-      if (w.sub_wait[b] > 0) { if (threadIdx.x == 0) w.sub_wait[b] -= 1; return; }     // backing off after a failed call
+      if (w.ws_first) {      // decided before this iteration (k_global): the full kernel runs this slot beside us and may re-seed sub_on / Xs meanwhile
+        if (w.ws_first[b]) { if (threadIdx.x == 0 && w.sub_wait[b] > 0) w.sub_wait[b] -= 1; return; }
+      } else {
+        if (!w.sub_on[b]) return;
+        if (w.sub_wait[b] > 0) { if (threadIdx.x == 0) w.sub_wait[b] -= 1; return; }     // backing off after a failed call
+      }
     } else {
       if (!w.sub_onC[b]) { if (threadIdx.x == 0) w.confirm[b] = 1; return; }           // no block yet: the full kernel evaluates (and seeds)
     }
@@ -1517,7 +1736,7 @@ __global__ void __launch_bounds__(256) k_cone_sub(OmcWS w) {
           if (!(evj[t] <= tol_eff * nF * scale)) bad = 1;
         }
       }
-      s_flag = (nk > SUBP - SUBG) ? 2 : (bad ? 0 : 1);
+      s_flag = (nk > SUBP - w.sub_guard) ? 2 : (bad ? 0 : 1);
     }
     __syncthreads();
     SUBSTAMP(9);
@@ -2158,7 +2377,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
   rd2 = block_sum(rd2, red);
   fr2 = block_sum(fr2, red);
   tr1 = block_sum(tr1, red);
-  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.fro2[b] = fr2; w.trM[b] = tr1; w.cone_done[b] = 0; w.iters[b] += 1; DIAG_CYC(4, b); }
+  if (tid == 0) { w.rp[b] = sqrt(rp2); w.rd[b] = sqrt(rd2); w.fro2[b] = fr2; w.trM[b] = tr1; w.cone_done[b] = 0; w.iters[b] += 1; if (w.ws_first) w.ws_first[b] = (!w.sub_on[b] || w.sub_wait[b] > 0) ? 1 : 0; DIAG_CYC(4, b); }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2632,7 +2851,12 @@ extern "C" {
 void omc_launch_setup(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s) {
   const int wpb = 4;
-  const int waves = w->nB * w->m;
+  if (mode == 0 && w->cp_pair) {
+    const int wp = w->nB * ((w->m + 1) / 2);
+    hipLaunchKernelGGL(k_colprox_pair, dim3((wp + wpb - 1) / wpb), dim3(wpb * 64), (size_t)wpb * CPP_LDS_DOUBLES * sizeof(double), s, *w);
+    if (w->cp_nsolo == 0) return;
+  }
+  const int waves = w->nB * ((mode == 0 && w->cp_pair) ? w->cp_nsolo : w->m);
   const int blocks = (waves + wpb - 1) / wpb;
   hipLaunchKernelGGL(k_colprox, dim3(blocks), dim3(wpb * 64), (size_t)wpb * w->cp_lds_doubles * sizeof(double), s, *w, mode);
 }
