@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--warm", type=int, default=int(os.environ.get("OMC_BENCH_WARM", 1)), help="1: every node starts from its parent's final state (omc_relax_set_warm), as in a B&B run where "
                     "a child is relaxed after its parent -- the ancestors are relaxed level by level before the timed region, each from its own parent's state; "
                     "2: only the frontier's parents are relaxed beforehand, cold; 0: cold starts (the reference rebuilds every model, OMC.jl:1482)")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("OMC_BENCH_PIPELINE", 1)), help="1: the K timed steps are K batches handed to the engine as one stream (continuous batching: "
+                    "the slots a batch frees while its last nodes converge are refilled from the next batch, as a B&B queue that always holds open nodes would); "
+                    "0: each step is staged, solved and drained on its own (rounds 1-2)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip latency_b1 / branching / time_to_gap / cpu_baseline (rank 0, N=1 only)")
     return ap.parse_args()
 
@@ -82,25 +85,34 @@ def spawn_ranks(args):
 
 
 def cpu_baseline_legs(A, mask, gamma, k, cut_type, rho_scale, nodes, depth):
-    """The CPU restatement (oracle/omc_oracle.py: same formulation, same tolerances, LAPACK) on the host cores of this box: (a) one
-    thread, mirroring MSK_IPAR_NUM_THREADS=1 of the reference (OMC.jl:1486), (b) every core with node-level parallelism (one
-    single-threaded worker per core).  The reference itself (Julia + Mosek) cannot run here."""
-    import multiprocessing as mp
+    """The CPU restatement of the node relaxation on the host cores of this box, timed AFTER the GPU region (rank 0, N = 1):
+    (a) `value`: the compiled single-thread restatement (oracle/omc_cpu_ref.cpp, checked against the numpy oracle in tests/test_cpu_ref.py)
+        on one thread -- the way the reference pins its solver (MSK_IPAR_NUM_THREADS = 1, OMC.jl:1486);
+    (b) `all_cores`: the same library with OpenMP over independent nodes, one node per host core, every core of the box;
+    (c) `numpy_port`: the numpy / LAPACK oracle (oracle/omc_oracle.py) pinned to one thread, as in rounds 1-2.
+    Cold starts (the reference rebuilds every model, OMC.jl:1482).  The reference itself (Julia + Mosek) cannot run here."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import omc_oracle as orc
+    import omc_cpu_ref as cref
     nproc = os.cpu_count() or 1
+    inst = orc.Instance(A, mask, gamma, k)
+    P = orc.RelaxParams(); P.rho_scale = rho_scale
     t1 = time.perf_counter()
-    one = _cpu_worker((A, mask, gamma, k, cut_type, rho_scale, nodes))
+    one, _ = cref.relax_nodes(inst, nodes, cut_type, params=P, threads=1)
     t_one = time.perf_counter() - t1
-    workers = max(1, min(nproc, int(os.environ.get("OMC_BENCH_CPU_WORKERS", nproc))))        # every host core (VERDICT r2: the leg used 16 of 256)
+    workers = max(1, min(nproc, int(os.environ.get("OMC_BENCH_CPU_WORKERS", nproc))))
     sample = [nodes[i % len(nodes)] for i in range(workers)]
-    ctx = mp.get_context("spawn")
     t1 = time.perf_counter()
-    with ctx.Pool(workers) as pool:
-        pool.map(_cpu_worker, [(A, mask, gamma, k, cut_type, rho_scale, [c]) for c in sample])
+    cref.relax_nodes(inst, sample, cut_type, params=P, threads=workers)
     t_all = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    its_np = _cpu_worker((A, mask, gamma, k, cut_type, rho_scale, nodes[:2]))
+    t_np = time.perf_counter() - t1
     return dict(value=len(nodes) / t_one, unit="node-relaxations/s", cores=1, kind="port", nproc=nproc,
-                sample=f"first {len(nodes)} nodes of the depth-{depth} frontier, numpy/LAPACK oracle pinned to 1 thread (threadpoolctl); iterations {one}; "
-                       "the reference itself (Julia + Mosek) cannot run here",
-                all_cores=dict(value=len(sample) / t_all, cores=workers, sample=f"{len(sample)} nodes, one single-threaded worker process per core (node-level parallelism), pool start-up included"))
+                sample=f"first {len(nodes)} nodes of the depth-{depth} frontier, cold starts, compiled single-thread restatement (oracle/omc_cpu_ref.cpp, g++ -O3); "
+                       f"iterations {[o['iters'] for o in one]}, status {[o['status_code'] for o in one]}; the reference itself (Julia + Mosek) cannot run here",
+                all_cores=dict(value=len(sample) / t_all, cores=workers, sample=f"{len(sample)} nodes (the same {len(nodes)}, repeated), OpenMP over the nodes: one single-threaded node per core, {workers} threads"),
+                numpy_port=dict(value=len(nodes[:2]) / t_np, cores=1, sample=f"first {len(nodes[:2])} nodes, numpy / LAPACK oracle pinned to one thread (threadpoolctl); iterations {its_np}"))
 
 
 def _cpu_worker(job):
@@ -223,9 +235,7 @@ def main():
             eng.matrix_completion_SDP_relaxation([c for _, c in lev], cfg["cut_type"], params=P, want_Y=False, want_X=False, load_from=lf, save_to=[pidx[key] for key, _ in lev])
     eng.stage(nodes, cfg["cut_type"], P, load_from=load_from)           # node descriptors (and parent states) resident in HBM before the timed region
 
-    def step():
-        eng.solve()
-        out = eng.fetch(want_Y=False, want_X=False)
+    def exchange(out):
         ub = min(o["objective"] for o in out); lb = min(o["dual_bound"] for o in out)
         if use_comm and lib_comm:
             ub, lb, _ = eng.allreduce_bounds(ub, lb)
@@ -233,7 +243,12 @@ def main():
             t = torch.tensor([ub, lb], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ub, lb = float(t[0]), float(t[1])
-        return (ub, lb), out
+        return ub, lb
+
+    def step():
+        eng.solve()
+        out = eng.fetch(want_Y=False, want_X=False)
+        return exchange(out), out
 
     # every launch of the timed steps is bracketed by HIP events: hipGraph replay of the iteration body (the library's path for <= 16 live
     # slots, whose kernels events cannot see) is switched off for them, so that the per-kernel averages below and rocprofv3's describe the
@@ -250,9 +265,20 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    pipelined = bool(args.pipeline) and args.steps > 1
+    if pipelined:      # the K batches as one stream: node b of batch s is node s * B + b (descriptors and parent states resident before the clock starts)
+        eng.stage(nodes * args.steps, cfg["cut_type"], P, load_from=None if load_from is None else load_from * args.steps)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, out = step()
+    for s_ in range(1 if pipelined else args.steps):
+        if pipelined:
+            eng.solve()
+            out_all = eng.fetch(want_Y=False, want_X=False)
+            for q in range(args.steps):                      # one bound exchange per batch, as in the step-by-step form
+                exchange(out_all[q * B:(q + 1) * B])
+            out = out_all[(args.steps - 1) * B:]
+        else:
+            _, out = step()
         for c, v in eng.kernel_stats().items():
             a = kstats.setdefault(c, dict(launches=0, ms=0.0, units=0))
             a["launches"] += v["launches"]; a["ms"] += v["ms"]; a["units"] += v["units"]
@@ -422,8 +448,9 @@ def main():
             "config": {"workload": f"config {args.config}: {n}x{m} rank-{k}, gamma=80, 20% observed, {cfg['cut_type']} cuts, smallest_1_eigvec; "
                                    f"{B} depth-{args.depth} frontier nodes per GPU per step streamed through {min(args.slots, B)} slots (continuous batching, "
                                    + ("every node warm-started from its parent's final state" if args.warm else "cold starts")
-                                   + (", each rank its own subtrees" if world > 1 else "") + ")",
-                       "nodes_per_gpu": B, "slots": min(args.slots, B), "warm_start": bool(args.warm), "parent_states_in_pool": n_parents, "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
+                                   + (", each rank its own subtrees" if world > 1 else "")
+                                   + (f"; the {args.steps} steps are {args.steps} batches handed over as one stream: slots freed while a batch's last nodes converge are refilled from the next batch" if pipelined else "") + ")",
+                       "nodes_per_gpu": B, "slots": min(args.slots, B), "pipelined_batches": pipelined, "warm_start": bool(args.warm), "parent_states_in_pool": n_parents, "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
                        "status_counts": {"optimal": int(status[0]), "slow_progress": int(status[1]), "time_limit": int(status[2]), "infeasible": int(status[3])},
                        "certified_fraction": certified / B, "certified_nodes_per_s": value, "nodes_per_s_all": value_all,
                        "bounds_exchange": (comm_kind if use_comm else None),

@@ -469,14 +469,16 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
 
 // ---------------------------------------------------------------------------------------------------------
 // k_colprox_pair: the column prox (mode 0 of k_colprox) with TWO columns per wave.  A column of config 2 has ~20 observed rows: with one
-// column per wave 20 of 64 lanes worked, and the factorisation spent most of its instructions on v_readlane broadcasts (SGPR round trips).
-// Here each half-wave (32 lanes) owns one column, lane l of a half owns matrix row l, and the whole row lives in REGISTERS:
-//   R[q], q < l   strictly lower part (A = B + cp s I on entry, the unit-lower factor L on exit; zero on and above the diagonal),
-//   dg            the diagonal entry (the pivot d_l on exit).
-// Right-looking L D L': at step k every lane stages its entry of column k in LDS (one ds_write), and reads pivot and the column entries of the
-// other rows back as half-uniform (broadcast) ds_reads -- no cross-lane VALU traffic in the O(c^2) part, one fma per (row, k, q).
-// Forward substitution: one half-wave broadcast per step (DPP row_newbcast + v_permlane16_swap, no SGPR); backward substitution in
-// inner-product form: one half-wave sum per step (DPP adds + v_permlane16_swap).  B stays in registers for the second factorisation.
+// column per wave 20 of 64 lanes worked, and the factorisation spent most of its instructions on v_readlane broadcasts (SGPR round trips)
+// and its solves on a dependent chain of one broadcast per row.  Here each half-wave (32 lanes) owns one column, lane l of a half owns
+// matrix row l, and the whole row lives in REGISTERS.  Instead of a factorisation and triangular solves the half computes the inverse:
+//   -(B + cp s I)^-1 by the symmetric sweep operator (the Gauss-Jordan form that keeps the matrix symmetric, so that row k is available as
+//   column k): at step k every lane stages its entry of column k in LDS (one ds_write), reads the pivot and the column back as
+//   half-uniform (broadcast) ds_reads and updates its row with one fma per entry -- no cross-lane VALU traffic, no SGPR round trip;
+//   the pivots are those of L D L', so their sign is the positive-definiteness test the secular iteration needs;
+//   every solve (y = A^-1 a, z = A^-1 y, w = A^-1 z) is then one staged vector and 32 fma per lane, with no dependent chain.
+// (A first form with L D L' in registers and substitutions by DPP row_newbcast / v_permlane16_swap broadcasts took 813 us per launch at
+// ~950 live slots against 620 us for this one and 1111 us for k_colprox; the launch is bound by the LDS return path of the broadcast reads.)
 // The secular iteration of colprox_reg is carried per half (all of its scalars are half-uniform lane values); a half that has finished
 // idles while the other one goes on.  Columns with more than 32 rows and unpaired last columns stay with k_colprox (w.cp_solo).
 // ---------------------------------------------------------------------------------------------------------
@@ -535,12 +537,12 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
   sidx[lane] = my; vo_s[lane] = vo_r;
   const double rho_f = w.rho_b[b] * w.rho_f_ratio;
   const double coef = gm / (2.0 * rho_f), cp = gm * gm / (2.0 * rho_f);
-  // ---- B = I + gamma ((2 Y - Yp)[O, O] - coef a_old a_old'): row l of the strictly lower triangle in registers, every load issued before its use
-  double Bq[CPP_C], Bd;
+  // ---- B = I + gamma ((2 Y - Yp)[O, O] - coef a_old a_old'): the whole row l in registers (entry (l, q) and entry (q, l) read the same
+  // element of Y: the matrix is symmetric bit for bit), every load of a batch issued before its first use.  The copy stays in registers for
+  // the second Halley step (measured: gathering it again from L2 instead, 167 VGPRs = three waves per SIMD, is slower -- the kernel is bound
+  // by the LDS return path of the broadcast reads, which a third wave only crowds)
+  double Bq[CPP_C];
   {
-    const size_t ad = (size_t)my * n + my;
-    const double yd = 2.0 * Y[ad] - Yp[ad];
-    Bd = act ? fma(gm, yd - coef * vo_r * vo_r, 1.0) : 1.0;
 #pragma unroll
     for (int qb = 0; qb < CPP_C; qb += 8) {
       if (qb < cmax) {
@@ -549,13 +551,14 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
         for (int u = 0; u < 8; ++u) {
           const int iq = sidx[hb + qb + u];
           vq[u] = vo_s[hb + qb + u];
-          const size_t a = (size_t)iq * n + my;
+          const size_t a = (l > qb + u) ? (size_t)iq * n + my : (size_t)my * n + iq;
           y1[u] = Y[a]; y2[u] = Yp[a];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+          const int q = qb + u;
           const double v = gm * ((2.0 * y1[u] - y2[u]) - coef * vo_r * vq[u]);
-          Bq[qb + u] = (act && l > qb + u) ? v : 0.0;
+          Bq[q] = (l == q) ? (act ? v + 1.0 : 1.0) : ((act && q < c) ? v : 0.0);      // rows / columns beyond the column's size: identity
         }
       } else {
 #pragma unroll
@@ -563,62 +566,62 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
       }
     }
   }
-  double R[CPP_C], dg, dinv;
-  // L D L' of B + shift I, both halves at once; returns (per half) whether every pivot was positive
-  auto factor = [&](double shift) -> bool {
-#pragma unroll
-    for (int q = 0; q < CPP_C; ++q) R[q] = Bq[q];
-    dg = Bd + shift;
-    bool good = true;
+  double R[CPP_C], sc;
+  // -(B + shift I)^-1 by the symmetric sweep operator, both halves at once.  Lane l holds row l as sc * R[q] (sc = 1 until the row has been
+  // the pivot row, 1 / d_l afterwards: the pivot row is never rescaled entry by entry).  Step k: every lane stages its entry of column k
+  // (= row k, by symmetry) in LDS, reads pivot and row back as half-uniform ds_reads and updates its row with one fma per entry.  The pivots
+  // are those of the L D L' factorisation, so their sign is the positive-definiteness test.  Returns (per half) whether every pivot was positive.
+  auto invert = [&](double shift) -> bool {
     int cm = cmax;
-    asm volatile("" : "+s"(cm));      // same for the wave-uniform guards (k < cmax): s_cmp + s_cbranch_scc where they stand
-    int lv = l;
-    asm volatile("" : "+v"(lv));      // opaque copy: the 64 lane masks (l == k, l > k) are compared where they are used -- hoisted out of the secular loop they were spilled to VGPR lanes (v_writelane / v_readlane + s_nop per use)
+    asm volatile("" : "+s"(cm));      // opaque copies: the guards (k < cmax) and lane masks (l == k) are evaluated where they stand -- hoisted out
+    int lv = l;                       // of the secular loop they were spilled to VGPR lanes (v_writelane / v_readlane + s_nop per use)
+    asm volatile("" : "+v"(lv));
+#pragma unroll
+    for (int q = 0; q < CPP_C; ++q) R[q] = (lv == q) ? Bq[q] + shift : Bq[q];
+    sc = 1.0;
+    double isc = 1.0;
+    bool good = true;
 #pragma unroll
     for (int k = 0; k < CPP_C; ++k) {
       if (k < cm) {                                              // wave-uniform
-        st[lane] = (lv == k) ? dg : R[k];
+        const double ak = R[k] * sc;                             // a(l, k); lane k: the pivot
+        st[lane] = ak;
         const double d = st[hb + k];
         good = good && (d > 1e-290);
         const double pinv = fast_rcp(d);
-        const double lk = (lv > k) ? R[k] * pinv : 0.0;         // unit-lower entry L(l, k); zero on and above the diagonal
-        dg = fma(-lk, R[k], dg);
+        const bool piv = (lv == k);
+        const double tt = piv ? 0.0 : ak * pinv * isc;           // a(l, k) / d in units of this lane's scale; the pivot row itself is not touched
 #pragma unroll
         for (int qb = 0; qb < CPP_C; qb += 4) {
-          if (qb + 3 > k && qb < cm) {                         // wave-uniform; rows beyond a column's size hold zeros
+          if (qb < cm) {                                         // wave-uniform; rows beyond a column's size are identity rows
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int q = qb + u;
-              if (q > k) R[q] = fma(-lk, st[hb + q], R[q]);
+              if (q != k) R[q] = fma(-tt, st[hb + q], R[q]);
             }
           }
         }
-        R[k] = lk;
+        R[k] = piv ? -1.0 : tt;                                  // column k: a(l, k) / d ; pivot: -1 / d = -1 * (new scale)
+        sc = piv ? pinv : sc;
+        isc = piv ? d : isc;
       }
     }
-    dinv = fast_rcp(dg);
     return good;
   };
-  // x = (L D L')^-1 rhs, vector in registers (lane = entry)
-  auto solve = [&](double rhs) -> double {
+  // x = (B + shift I)^-1 v: the vector is staged in LDS and every lane takes the inner product with its row (four partial sums)
+  auto apply = [&](double v) -> double {
     int cm = cmax;
     asm volatile("" : "+s"(cm));
-    double f = rhs;
-    static_for<0, CPP_C - 1>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      if (q + 1 < cm) f = fma(-R[q], half_bcast<q>(f), f);     // R[q] = 0 in lanes l <= q
-    });
-    double x = f * dinv;
-    int lv = l;
-    asm volatile("" : "+v"(lv));
-    static_for<0, CPP_C - 1>([&](auto ic) {
-      constexpr int q = CPP_C - 2 - decltype(ic)::value;
-      if (q + 1 < cm) {
-        const double sm_ = half_sum(R[q] * x);                   // sum over l > q of L(l, q) x_l
-        x = (lv == q) ? x - sm_ : x;
+    st[lane] = v;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int qb = 0; qb < CPP_C; qb += 4) {
+      if (qb < cm) {
+        a0 = fma(R[qb], st[hb + qb], a0); a1 = fma(R[qb + 1], st[hb + qb + 1], a1);
+        a2 = fma(R[qb + 2], st[hb + qb + 2], a2); a3 = fma(R[qb + 3], st[hb + qb + 3], a3);
       }
-    });
-    return x;
+    }
+    return -sc * ((a0 + a1) + (a2 + a3));
   };
   // ---- secular equation || (B + cp s I)^-1 a ||^2 = s: Halley steps with the Taylor finish of colprox_reg, per half.  ONE instance of the
   // factorisation and ONE of the solve in the instruction stream (the inlined code of both is ~2.5 k instructions): the solves of a pass
@@ -632,11 +635,11 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
   for (int it = 0; it <= 60; ++it) {
     if (!__any(!fin)) break;
     const bool last = (it == 60);
-    const bool ok_ = factor(cp * s);
+    const bool ok_ = invert(cp * s);
     double yr = 0.0, zr = 0.0, rhs = a_reg;
     bool want_w = false; double dstep = 0.0, snext = s;
     for (int sv = 0; sv < 3; ++sv) {
-      const double x = solve(rhs);
+      const double x = apply(rhs);
       rhs = x;
       if (sv == 0) {
         yr = x;
