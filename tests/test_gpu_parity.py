@@ -1037,3 +1037,69 @@ def test_config5_node_evaluation(have_gpu, omc, orc):
     w = np.linalg.eigvalsh(o["Y"])
     assert w[0] >= -1e-2 and w[-1] <= 1 + 1e-2 and np.trace(o["Y"]) <= 2 + 1e-6
     eng.close()
+
+
+def _env_run(eng, omc, nodes, P, env):
+    old = {k_: os.environ.get(k_) for k_ in env}
+    os.environ.update(env)
+    try:
+        return eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_X=False)
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                del os.environ[k_]
+            else:
+                os.environ[k_] = v
+
+
+def test_colprox_pair_kernel_against_one_column_kernel(have_gpu, omc, orc):
+    """k_colprox_pair (two columns per wave, inverse by the symmetric sweep operator in registers) against k_colprox (one column per wave,
+    L D L' in LDS) on the same nodes at a fixed iteration count: the two are different arithmetic for the same prox, so they agree to
+    round-off amplified by the ADMM map, not bit for bit.  Second instance: odd m (unpaired last column), columns with more than 32
+    observed rows (they stay with k_colprox: w.cp_solo) next to sparse ones, and an empty column."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(2, seed=0)
+    eng = omc.Engine(A, mask, gamma, 1)
+    P = omc.default_params(rho_scale=4.0, max_iters=300, eps_gap=1e-14)
+    nodes, _ = omc.pkg.bnb.expand_frontier(eng, 3, "linear", params=omc.default_params(rho_scale=4.0))
+    a = _env_run(eng, omc, nodes, P, {})
+    b = _env_run(eng, omc, nodes, P, {"OMC_NO_COLPROX_PAIR": "1"})
+    for x, y in zip(a, b):
+        assert x["iters"] == y["iters"] == 300
+        assert x["objective"] == pytest.approx(y["objective"], rel=1e-9) and x["dual_bound"] == pytest.approx(y["dual_bound"], rel=1e-8, abs=1e-8)
+        assert np.allclose(x["Y"], y["Y"], atol=1e-9)
+    eng.close()
+    rng = np.random.default_rng(11)
+    n, m = 40, 45
+    dens = rng.choice([0.15, 0.5, 0.95], size=m)
+    mask = rng.random((n, m)) < dens[None, :]
+    mask[:, 7] = False                                   # an empty column
+    mask[0, :7] = True; mask[1, 8:] = True               # every row observed somewhere
+    U0 = rng.standard_normal((n, 1)); V0 = rng.standard_normal((1, m))
+    A = (U0 @ V0 + 0.01 * rng.standard_normal((n, m))) * mask
+    assert (mask.sum(0) > 32).any() and (mask.sum(0) <= 32).any()
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    inst = orc.Instance(A, mask, GAMMA, 1)
+    P = omc.default_params(rho_scale=4.0)
+    got = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P)[0]
+    ref = orc.sdp_relaxation(inst, [], "linear", params=orc.RelaxParams(rho_scale=4.0))
+    assert got["status_code"] == 0 and ref["termination_status"] == 0
+    assert got["objective"] == pytest.approx(ref["objective"], rel=2e-6) and got["dual_bound"] == pytest.approx(ref["dual_bound"], rel=2e-6)
+    eng.close()
+
+
+def test_split_launch_of_the_full_eigen_kernel_is_bit_identical(have_gpu, omc):
+    """The full eigen-kernel as a known-in-advance launch beside k_cone_sub plus an (almost empty) launch behind it, against one launch
+    after k_cone_sub (OMC_NO_WS_SPLIT): the same kernel runs each slot either way, so every result is bit-identical; likewise event timing
+    of every 8th iteration only (OMC_TIMING_STRIDE), which changes what is measured and not what is computed."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(2, seed=0)
+    eng = omc.Engine(A, mask, gamma, 1)
+    P = omc.default_params(rho_scale=4.0, max_iters=400)
+    nodes, _ = omc.pkg.bnb.expand_frontier(eng, 5, "linear", params=P)
+    a = _env_run(eng, omc, nodes, P, {})
+    b = _env_run(eng, omc, nodes, P, {"OMC_NO_WS_SPLIT": "1"})
+    c_ = _env_run(eng, omc, nodes, P, {"OMC_TIMING_STRIDE": "8"})
+    for x, y, z in zip(a, b, c_):
+        for key in ("objective", "dual_bound", "iters", "status_code"):
+            assert x[key] == y[key] == z[key], key
+        assert np.array_equal(x["Y"], y["Y"]) and np.array_equal(x["Y"], z["Y"])
+    eng.close()
