@@ -458,7 +458,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   int rc_ = 0;
   if ((rc_ = upload(h->dwY, wY.data(), sizeof(double) * n * n, h->stream))) return rc_;
   w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
-  w.cp_pair = getenv("OMC_NO_COLPROX_PAIR") ? 0 : 1; w.cp_nsolo = h->nsolo; w.cp_solo = h->nsolo ? h->dsolo.as<int>() : nullptr;
+  w.cp_pair = getenv("OMC_NO_COLPROX_PAIR") ? 0 : 1; w.cp_series = getenv("OMC_CP_SERIES") ? atoi(getenv("OMC_CP_SERIES")) : 6; w.cp_maxpass = getenv("OMC_CP_MAXPASS") ? atoi(getenv("OMC_CP_MAXPASS")) : 60; w.cp_nsolo = h->nsolo; w.cp_solo = h->nsolo ? h->dsolo.as<int>() : nullptr;
   w.Ncnt = h->dNcnt.as<double>(); w.wY1 = h->dwY.as<double>();
   w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>();
 #define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)

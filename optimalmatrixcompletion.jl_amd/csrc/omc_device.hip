@@ -505,7 +505,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 #define CPP_LDS_DOUBLES (64 + 64 + 32)      // per wave: staged column, previous alpha, row indices (64 ints)
 
-__global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_colprox_pair(OmcWS w) {
   extern __shared__ double smem[];
   const int wave_in_blk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, wpb = blockDim.x >> 6;      // scalar: every guard below is a wave-uniform branch
   const int gw = blockIdx.x * wpb + wave_in_blk;
@@ -537,12 +537,11 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
   sidx[lane] = my; vo_s[lane] = vo_r;
   const double rho_f = w.rho_b[b] * w.rho_f_ratio;
   const double coef = gm / (2.0 * rho_f), cp = gm * gm / (2.0 * rho_f);
-  // ---- B = I + gamma ((2 Y - Yp)[O, O] - coef a_old a_old'): the whole row l in registers (entry (l, q) and entry (q, l) read the same
-  // element of Y: the matrix is symmetric bit for bit), every load of a batch issued before its first use.  The copy stays in registers for
-  // the second Halley step (measured: gathering it again from L2 instead, 167 VGPRs = three waves per SIMD, is slower -- the kernel is bound
-  // by the LDS return path of the broadcast reads, which a third wave only crowds)
-  double Bq[CPP_C];
-  {
+  // ---- B + shift I, B = I + gamma ((2 Y - Yp)[O, O] - coef a_old a_old'): the whole row l in registers (entry (l, q) and entry (q, l) read the
+  // same element of Y: the matrix is symmetric bit for bit), every load of a batch issued before its first use.  The rare second inversion
+  // (3 % of the columns since the series finish) gathers the matrix again from L2: a copy kept in registers (64 VGPRs) costs a wave per SIMD
+  double R[CPP_C], sc;
+  auto gather = [&](double shift) {
 #pragma unroll
     for (int qb = 0; qb < CPP_C; qb += 8) {
       if (qb < cmax) {
@@ -558,26 +557,23 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
         for (int u = 0; u < 8; ++u) {
           const int q = qb + u;
           const double v = gm * ((2.0 * y1[u] - y2[u]) - coef * vo_r * vq[u]);
-          Bq[q] = (l == q) ? (act ? v + 1.0 : 1.0) : ((act && q < c) ? v : 0.0);      // rows / columns beyond the column's size: identity
+          R[q] = (l == q) ? (act ? v + 1.0 : 1.0) + shift : ((act && q < c) ? v : 0.0);      // rows / columns beyond the column's size: identity
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) Bq[qb + u] = 0.0;
+        for (int u = 0; u < 8; ++u) R[qb + u] = 0.0;
       }
     }
-  }
-  double R[CPP_C], sc;
+  };
   // -(B + shift I)^-1 by the symmetric sweep operator, both halves at once.  Lane l holds row l as sc * R[q] (sc = 1 until the row has been
   // the pivot row, 1 / d_l afterwards: the pivot row is never rescaled entry by entry).  Step k: every lane stages its entry of column k
   // (= row k, by symmetry) in LDS, reads pivot and row back as half-uniform ds_reads and updates its row with one fma per entry.  The pivots
   // are those of the L D L' factorisation, so their sign is the positive-definiteness test.  Returns (per half) whether every pivot was positive.
-  auto invert = [&](double shift) -> bool {
+  auto invert = [&]() -> bool {
     int cm = cmax;
     asm volatile("" : "+s"(cm));      // opaque copies: the guards (k < cmax) and lane masks (l == k) are evaluated where they stand -- hoisted out
     int lv = l;                       // of the secular loop they were spilled to VGPR lanes (v_writelane / v_readlane + s_nop per use)
     asm volatile("" : "+v"(lv));
-#pragma unroll
-    for (int q = 0; q < CPP_C; ++q) R[q] = (lv == q) ? Bq[q] + shift : Bq[q];
     sc = 1.0;
     double isc = 1.0;
     bool good = true;
@@ -632,21 +628,34 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
   double lo = 0.0, hi = -1.0;
   bool lo_valid = false, fin = (c == 0);
   double yout = 0.0;
+  // One inversion per ADMM iteration in the common case.  After the Halley step d from (y, z) the answer at s + d is read off the Neumann
+  // series  alpha(s + d) = sum_k (-cp d)^k A^-(k+1) a  instead of a second inversion: the vectors v_k = A^-k a are one cheap product with the
+  // inverse each, the moments m_p = a' A^-p a = <v_i, v_j> (i + j = p) give ||alpha_K(s + d)||^2 as a polynomial in d, and the secular
+  // equation of the TRUNCATED alpha_K is solved for d by scalar Newton steps (so the returned pair satisfies ||alpha||^2 = s to round-off);
+  // accepted when the first term left out is below 2e-15 of the first kept.  K = 3 (colprox_reg's second-order finish) when cp |d| ||z|| / ||y|| < 1e-5,
+  // else K = 6, which carries steps up to cp |d| ||A^-1|| ~ 5e-3 -- the size s moves per ADMM iteration until late in a solve; with K = 3
+  // alone the kernel averaged more than two inversions per column pair.  A step the series cannot carry is taken as before (s <- s + d, invert).
+  const int ser_max = (w.cp_series > 0) ? w.cp_series : 3;
+  int npass = 0; double dr_first = -1.0; int why = 0;      // diagnostics (OMC_SUB_DEBUG=4)
   for (int it = 0; it <= 60; ++it) {
     if (!__any(!fin)) break;
-    const bool last = (it == 60);
-    const bool ok_ = invert(cp * s);
-    double yr = 0.0, zr = 0.0, rhs = a_reg;
-    bool want_w = false; double dstep = 0.0, snext = s;
-    for (int sv = 0; sv < 3; ++sv) {
+    const bool last = (it >= w.cp_maxpass);
+    gather(cp * s);
+    const bool ok_ = invert();
+    if (!fin) ++npass;
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double rhs = a_reg, yy = 0.0, yz = 0.0, zz = 0.0;
+    bool want_ser = false; double dstep = 0.0;
+    int K = 2;
+    for (int sv = 0; sv < K; ++sv) {
       const double x = apply(rhs);
       rhs = x;
-      if (sv == 0) {
-        yr = x;
-        if (last) { if (!fin) { yout = yr; fin = true; } break; }
-      } else if (sv == 1) {
-        zr = x;
-        const double yy = half_sum(yr * yr), yz = half_sum(yr * zr), zz = half_sum(zr * zr);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) v[q] = (sv == q) ? x : v[q];
+      if (sv == 0 && last) { if (!fin) { yout = x; fin = true; } break; }
+      if (sv == 1) {
+        yy = half_sum(v[0] * v[0]); yz = half_sum(v[0] * v[1]); zz = half_sum(v[1] * v[1]);
+        bool big = false;
         if (!fin) {
           if (!ok_) {                                              // s below the positive definite range: move right
             lo = s; lo_valid = false;
@@ -661,16 +670,66 @@ __global__ void __launch_bounds__(256) k_colprox_pair(OmcWS w) {
             if (sn < lo) { sn = lo; guarded = true; }
             if (hi > 0.0 && sn > hi) { sn = 0.5 * (lo + hi); guarded = true; }
             const double d = sn - s;
-            if (fabs(d) <= 1e-13 * fmax(1.0, fabs(s))) { fin = true; yout = yr; }      // the current solve is the answer
-            else if (!guarded && yy > 0.0 && cp * fabs(d) * sqrt(zz / yy) < 1e-5) { want_w = true; dstep = d; snext = sn; }
+            const double dr = (yy > 0.0) ? cp * fabs(d) * sqrt(zz / yy) : 1.0;
+            if (dr_first < 0.0) { dr_first = dr; why = guarded ? 1 : 0; }
+            if (fabs(d) <= 1e-13 * fmax(1.0, fabs(s))) { fin = true; yout = v[0]; }      // the current solve is the answer
+            else if (!guarded && dr < ((ser_max >= 6) ? 5e-3 : 1e-5)) { want_ser = true; dstep = d; big = dr >= 1e-5; }
             else s = sn;
           }
         }
-        if (!__any(want_w)) break;
-      } else if (want_w) {                                         // alpha(s + d) = y - cp d z + cp^2 d^2 w, w = A^-1 z
-        yout = yr - cp * dstep * (zr - cp * dstep * x); s = snext; fin = true;
+        if (__any(want_ser)) K = __any(want_ser && big) ? 6 : 3;
       }
     }
+    if (K > 2) {
+      // moments m_2 .. m_2K of the half's column (m_2 = yy, m_3 = yz, m_4 = zz)
+      double mo[13];
+      mo[2] = yy; mo[3] = yz; mo[4] = zz;
+#pragma unroll
+      for (int i = 2; i < 6; ++i) {
+        if (i < K) { mo[2 * i + 1] = half_sum(v[i - 1] * v[i]); mo[2 * i + 2] = half_sum(v[i] * v[i]); }
+        else { mo[2 * i + 1] = 0.0; mo[2 * i + 2] = 0.0; }
+      }
+      if (want_ser) {
+        // G(t) = || sum_{k < K} (-t)^k v_{k+1} ||^2 = sum_p cnt(p) m_p (-t)^(p-2), t = cp d ; solve G(cp d) = s + d
+        double cf[11];
+#pragma unroll
+        for (int p = 2; p <= 12; ++p) {
+          const int cnt = (p <= K + 1) ? p - 1 : ((p <= 2 * K) ? 2 * K - p + 1 : 0);
+          cf[p - 2] = (double)cnt * mo[p];
+        }
+        double d = dstep;
+        bool conv = false;
+        for (int nt = 0; nt < 8; ++nt) {
+          const double t = -cp * d;
+          double G = 0.0, dG = 0.0;
+#pragma unroll
+          for (int q = 10; q >= 0; --q) { dG = fma(dG, t, G); G = fma(G, t, cf[q]); }      // Horner: G and dG / dt
+          const double F = G - s - d, dF = -cp * dG - 1.0;
+          const double dn = d - F / dF;
+          conv = fabs(dn - d) <= 1e-14 * fmax(fabs(s), fabs(dn));
+          d = dn;
+          if (conv) break;
+        }
+        const double t = cp * d;
+        const double t2 = t * t;
+        const double lastterm = ((K == 6) ? t2 * t2 * fabs(t) : t2) * sqrt(fmax((K == 6) ? mo[12] : mo[6], 0.0));      // |t|^(K-1) ||v_K||
+        const double growth = sqrt(fmax((K == 6) ? mo[12] : mo[6], 0.0) / fmax((K == 6) ? mo[10] : mo[4], 1e-300));      // ||v_K|| / ||v_(K-1)||: the ratios grow towards ||A^-1||
+        // the truncation error is the first term left out, ~ (last term kept) x |t| x growth
+        if (conv && s + d > lo * (lo_valid ? 1.0 : 0.0) && lastterm * fabs(t) * growth <= 2e-15 * sqrt(yy) && fabs(t) * growth < 0.05) {
+          double acc = 0.0;
+#pragma unroll
+          for (int q = 5; q >= 0; --q) acc = (q < K) ? fma(acc, -t, v[q]) : acc;
+          yout = acc; s = s + d; fin = true;
+        } else {
+          s = s + dstep;                                           // the series cannot carry this step: invert again at the Halley point
+        }
+      }
+    }
+  }
+  if (w.sub_debug == 4 && l == 0 && c > 0) {      // diagnostics: passes per column (stamps[0..7]), log10 of the first relative step (stamps[8..23]: bin 8 + min(15, -log10)), guarded first steps (24), failed first inversions (25)
+    atomicAdd(&w.stamps[(npass < 7) ? npass : 7], 1.0);
+    if (dr_first >= 0.0) { const int bin = (dr_first > 0.0) ? (int)fmin(15.0, fmax(0.0, -log10(dr_first))) : 15; atomicAdd(&w.stamps[8 + bin], 1.0); if (why) atomicAdd(&w.stamps[24], 1.0); }
+    else atomicAdd(&w.stamps[25], 1.0);
   }
   if (act) {
     alpha[l] = yout;
