@@ -278,9 +278,8 @@ def main():
     # every launch of the timed steps is bracketed by HIP events: hipGraph replay of the iteration body (the library's path for <= 16 live
     # slots, whose kernels events cannot see) is switched off for them, so that the per-kernel averages below and rocprofv3's describe the
     # same launches; the extras (latency_b1, branching) run with the library default
-    graph_env = os.environ.get("OMC_GRAPH_MAX")
     if os.environ.get("OMC_TIMING_STRIDE", "1") == "1":
-        os.environ["OMC_GRAPH_MAX"] = "0"
+        eng.tuning_set("OMC_GRAPH_MAX", "0")
     for _ in range(args.warmup):
         step()
     kstats = {}; sub = {}
@@ -374,10 +373,7 @@ def main():
                                 "the kernels back to back (profiles/ has both)",
                     kernel_ms=per_kernel, kernels=kernel_rooflines)
 
-    if graph_env is None:
-        os.environ.pop("OMC_GRAPH_MAX", None)
-    else:
-        os.environ["OMC_GRAPH_MAX"] = graph_env
+    eng.tuning_reload_env()                        # the extras run with the library default (or whatever the caller's environment says)
     extras = {}
     if rank == 0 and world == 1 and args.extras:
         # ---- single-node-at-a-time (BASELINE config 2 wording): batch 1, the reference's serial order --------------------------------
@@ -439,12 +435,11 @@ def main():
             e3 = omc_amd.Engine(A3, mask3, g3, 1, device=local)
             mi3 = e3.generate_rank1_matrix_completion_Shor_constraints_indexes([4])
             nb3 = int(os.environ.get("OMC_BENCH_SHOR_NODES", 8)); it3 = int(os.environ.get("OMC_BENCH_SHOR_ITERS", 400))
-            os.environ["OMC_GRAPH_MAX"] = "0"
+            e3.tuning_set("OMC_GRAPH_MAX", "0")
             e3.stage_shor([[]] * nb3, [(mi3, None)] * nb3, "linear", omc_amd.default_params(max_iters=it3, slots=nb3, eps_gap=1e-5))
             t1 = time.perf_counter(); e3.solve(); ts3 = time.perf_counter() - t1
             o3 = e3.fetch(want_Y=False, want_X=False)
             ks3 = {c_: round(v_["ms"], 1) for c_, v_ in e3.kernel_stats().items() if v_["launches"]}
-            os.environ.pop("OMC_GRAPH_MAX", None)
             extras["shor_config3"] = dict(workload=f"config 3: 200x200 rank-1, {len(mi3)} class-4 minors (device enumeration), {nb3} root copies, {it3} ADMM iterations each (a root certifies 1e-5 in ~2550: tests/test_gpu_shor.py)",
                                           minors=int(len(mi3)), node_iterations_per_s=nb3 * int(o3[0]["iters"]) / ts3, ms_per_iteration=ts3 / max(1, int(o3[0]["iters"])) * 1e3,
                                           kernel_ms=ks3, big_cone_order=int(A3.shape[0] + A3.shape[1]),

@@ -287,6 +287,12 @@ int omc_last_solver_info(omc_instance* h, double* info);
 int omc_last_subspace_stats(omc_instance* h, int64_t* out);
 /* the same eight counters for the order-(n+m) cone of the last Shor-mode solve */
 int omc_last_shor_subspace_stats(omc_instance* h, int64_t* out);
+/* Tuning / diagnostic knobs (OMC_STREAMS, OMC_GRAPH_MAX, OMC_NO_COLPROX_PAIR, ...: the list is OMC_TUNING_KEYS in omc_api.cpp, each documented
+ * where it is used).  The library reads the environment at omc_instance_create and nowhere else; omc_tuning_set overrides one knob of an
+ * instance (value NULL removes it), omc_tuning_reload_env reads the environment again.  No counterpart in the reference (its knobs are the
+ * Mosek parameters of OMC.jl:1482-1500). */
+int omc_tuning_set(omc_instance* h, const char* name, const char* value);
+int omc_tuning_reload_env(omc_instance* h);
 /* diagnostic builds (-DOMC_STAMPS) only: accumulated s_memtime ticks per kernel phase of node 0; zeros otherwise */
 int omc_debug_stamps(omc_instance* h, double* out32);
 /* diagnostic builds only: per-slot counters, out[c * slots + b]: c = 0 colprox wave cycles, 1 factorizations, 2 cone cycles,

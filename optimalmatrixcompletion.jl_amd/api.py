@@ -134,6 +134,15 @@ class Engine:
         except Exception:
             pass
 
+    # ---- tuning knobs ----------------------------------------------------------------------------------
+    def tuning_set(self, name, value=None):
+        """Set (or, with None, remove) one tuning knob of this instance (omc_tuning_set); the library reads the environment only at creation."""
+        _lib.check(self._lib.omc_tuning_set(self._h, name.encode(), None if value is None else str(value).encode()))
+
+    def tuning_reload_env(self):
+        """Read the OMC_* knobs from the environment again (omc_tuning_reload_env)."""
+        _lib.check(self._lib.omc_tuning_reload_env(self._h))
+
     # ---- relaxation ------------------------------------------------------------------------------------
     def state_pool_create(self, capacity):
         """Reserve `capacity` final states on the device for warm starts (omc_state_pool_create)."""

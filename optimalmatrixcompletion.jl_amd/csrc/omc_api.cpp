@@ -56,6 +56,56 @@ struct DevBuf {
   template <class T> T* as() { return (T*)p; }
 };
 
+// Tuning knobs.  The environment is read in ONE place -- tuning_from_env, called by omc_instance_create and by omc_tuning_reload_env -- and a
+// caller that does not want its environment to matter sets the knobs through omc_tuning_set; nothing else in the library calls getenv
+// (behaviour of the shipped library depended on the caller's environment at every solve, one knob even per iteration).
+static const char* const OMC_TUNING_KEYS[] = {
+  "OMC_ALTMIN_NOLDS",
+  "OMC_CERT_SUB",
+  "OMC_COLD_CHECK",
+  "OMC_COLPROX_FIRST",
+  "OMC_COLPROX_KEEPB",
+  "OMC_CONE_512",
+  "OMC_CP_MAXPASS",
+  "OMC_CP_SERIES",
+  "OMC_DEBUG_MAX_SWEEPS",
+  "OMC_DENSE_CHECK",
+  "OMC_GLOBAL_NOLDS",
+  "OMC_GRAPH_MAX",
+  "OMC_GROUPS",
+  "OMC_JACOBI_TAU",
+  "OMC_NO_COLPROX_PAIR",
+  "OMC_NO_GRAPH",
+  "OMC_NO_SEP_SUB",
+  "OMC_NO_SLOT_LIST",
+  "OMC_NO_SUBSPACE",
+  "OMC_NO_WARMSTART",
+  "OMC_NO_WS_SPLIT",
+  "OMC_REFILL_EVERY",
+  "OMC_SHOR_DEBUG",
+  "OMC_SHOR_EXPLICIT",
+  "OMC_SHOR_NO_SUBSPACE",
+  "OMC_SLOTS",
+  "OMC_SMALL_COLD",
+  "OMC_STREAMS",
+  "OMC_SUB_ADAPT",
+  "OMC_SUB_CHUNK",
+  "OMC_SUB_DEBUG",
+  "OMC_SUB_GUARD",
+  "OMC_SUB_LAZY",
+  "OMC_SUB_QMAX",
+  "OMC_SUB_TOL",
+  "OMC_TIMING_STRIDE",
+};
+struct Tuning {
+  std::unordered_map<std::string, std::string> kv;
+  const char* get(const char* name) const { auto it = kv.find(name); return it == kv.end() ? nullptr : it->second.c_str(); }
+};
+static void tuning_from_env(Tuning& t) {
+  t.kv.clear();
+  for (const char* key : OMC_TUNING_KEYS) if (const char* v = getenv(key)) t.kv[key] = v;
+}
+
 struct omc_instance {
   int n = 0, m = 0, k = 0, device = 0, nnz = 0, cmax = 0;
   double gamma = 0, sumA2 = 0;
@@ -66,6 +116,7 @@ struct omc_instance {
   DevBuf drow_ptr, drow_idx, drow_val, aR, arkind, arcut, arbi, arbj, arcoef, arrhs, acutx, aU0, aU, aV, aobj, aint, aG, aG2;
   hipStream_t stream = nullptr;
   // per slot group: main / column / small-cone streams and fork, join, done events (see omc_relax_solve)
+  Tuning tun;
   hipStream_t gs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t gev[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t ev_main = nullptr;
@@ -150,6 +201,7 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   if (device < 0 || device >= ndev) return fail(OMC_ERR_ARGUMENT, "device index out of range");
   HIPCHK(hipSetDevice(device));
   omc_instance* h = new omc_instance();
+  tuning_from_env(h->tun);
   struct Guard { omc_instance*& p; ~Guard() { if (p) omc_instance_destroy(p); } } guard{h};     // every early return below frees the handle
   h->n = n; h->m = m; h->k = k; h->gamma = gamma; h->device = device;
   h->A.assign(A, A + (size_t)n * m);
@@ -413,12 +465,12 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   memset(&w, 0, sizeof(w));
   // continuous batching: S slots relax B nodes; a slot that finishes is harvested and re-used for the next pending node
   int S = (P.slots > 0) ? std::min(P.slots, B) : std::min(B, 256);
-  if (getenv("OMC_SLOTS")) S = std::max(1, std::min(B, atoi(getenv("OMC_SLOTS"))));
+  if (h->tun.get("OMC_SLOTS")) S = std::max(1, std::min(B, atoi(h->tun.get("OMC_SLOTS"))));
   h->Btot = B;
   w.b0 = 0; w.nB = S;
   w.B = S; w.Btot = B; w.max_iters = P.max_iters; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
-  w.jacobi_tau = getenv("OMC_JACOBI_TAU") ? atof(getenv("OMC_JACOBI_TAU")) : 0.0;
-  w.max_sweeps = getenv("OMC_DEBUG_MAX_SWEEPS") ? atoi(getenv("OMC_DEBUG_MAX_SWEEPS")) : 30;
+  w.jacobi_tau = h->tun.get("OMC_JACOBI_TAU") ? atof(h->tun.get("OMC_JACOBI_TAU")) : 0.0;
+  w.max_sweeps = h->tun.get("OMC_DEBUG_MAX_SWEEPS") ? atoi(h->tun.get("OMC_DEBUG_MAX_SWEEPS")) : 30;
   w.breakpoints = P.breakpoints; w.stall_checks = P.stall_checks > 0 ? P.stall_checks : 1000000;
   w.gamma = h->gamma; w.sumA2 = h->sumA2;
   {
@@ -458,7 +510,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   int rc_ = 0;
   if ((rc_ = upload(h->dwY, wY.data(), sizeof(double) * n * n, h->stream))) return rc_;
   w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
-  w.cp_pair = getenv("OMC_NO_COLPROX_PAIR") ? 0 : 1; w.cp_series = getenv("OMC_CP_SERIES") ? atoi(getenv("OMC_CP_SERIES")) : 6; w.cp_maxpass = getenv("OMC_CP_MAXPASS") ? atoi(getenv("OMC_CP_MAXPASS")) : 60; w.cp_nsolo = h->nsolo; w.cp_solo = h->nsolo ? h->dsolo.as<int>() : nullptr;
+  w.cp_pair = h->tun.get("OMC_NO_COLPROX_PAIR") ? 0 : 1; w.cone_512 = h->tun.get("OMC_CONE_512") ? 1 : 0; w.cp_series = h->tun.get("OMC_CP_SERIES") ? atoi(h->tun.get("OMC_CP_SERIES")) : 6; w.cp_maxpass = h->tun.get("OMC_CP_MAXPASS") ? atoi(h->tun.get("OMC_CP_MAXPASS")) : 60; w.cp_nsolo = h->nsolo; w.cp_solo = h->nsolo ? h->dsolo.as<int>() : nullptr;
   w.Ncnt = h->dNcnt.as<double>(); w.wY1 = h->dwY.as<double>();
   w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>();
 #define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)
@@ -478,7 +530,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   HIPCHK(hipMemsetAsync(h->blamD.p, 0, sB * m * n * 8, h->stream));
   w.lamD = h->blamD.as<double>();
   w.lamDX = nullptr;
-  if (n > 144 || getenv("OMC_DENSE_CHECK") || shor) {      // large orders: the certificate matrix takes Lambda Lambda' from one MFMA product
+  if (n > 144 || h->tun.get("OMC_DENSE_CHECK") || shor) {      // large orders: the certificate matrix takes Lambda Lambda' from one MFMA product
     ENS(h->blamDX, sB * m * n * 8);
     HIPCHK(hipMemsetAsync(h->blamDX.p, 0, sB * m * n * 8, h->stream));
     w.lamDX = h->blamDX.as<double>();
@@ -491,15 +543,15 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     HIPCHK(hipMemsetAsync(h->bsubI.p, 0, sB * 14 * sizeof(int), h->stream));
     w.Xs = h->bXs.as<double>(); w.sub_theta = h->bsubS.as<double>(); w.trM = h->bsubS.as<double>() + sB * 16;
     w.sub_on = h->bsubI.as<int>(); w.cone_done = h->bsubI.as<int>() + sB; w.sub_stat = h->bsubI.as<int>() + 2 * sB; w.sub_wait = h->bsubI.as<int>() + 10 * sB; w.sub_nfail = h->bsubI.as<int>() + 11 * sB;
-    w.V3 = getenv("OMC_SMALL_COLD") ? nullptr : h->bsubS.as<double>() + sB * 17; w.v3valid = h->bsubI.as<int>() + 12 * sB;
+    w.V3 = h->tun.get("OMC_SMALL_COLD") ? nullptr : h->bsubS.as<double>() + sB * 17; w.v3valid = h->bsubI.as<int>() + 12 * sB;
     w.ws_first = h->bsubI.as<int>() + 13 * sB; w.ws_phase = 0;
-    w.sub_guard = getenv("OMC_SUB_GUARD") ? atoi(getenv("OMC_SUB_GUARD")) : 2;
-    w.sub_qmax = getenv("OMC_SUB_QMAX") ? atoi(getenv("OMC_SUB_QMAX")) : 24;
-    w.sub_chunk = getenv("OMC_SUB_CHUNK") ? atoi(getenv("OMC_SUB_CHUNK")) : 3;
-    w.sub_lazy = getenv("OMC_SUB_LAZY") ? atoi(getenv("OMC_SUB_LAZY")) : 1;
-    w.sub_tol = getenv("OMC_SUB_TOL") ? atof(getenv("OMC_SUB_TOL")) : 1e-10;
-    w.sub_adapt = getenv("OMC_SUB_ADAPT") ? atof(getenv("OMC_SUB_ADAPT")) : 1e-3;
-    w.sub_debug = getenv("OMC_SUB_DEBUG") ? atoi(getenv("OMC_SUB_DEBUG")) : 0;
+    w.sub_guard = h->tun.get("OMC_SUB_GUARD") ? atoi(h->tun.get("OMC_SUB_GUARD")) : 2;
+    w.sub_qmax = h->tun.get("OMC_SUB_QMAX") ? atoi(h->tun.get("OMC_SUB_QMAX")) : 24;
+    w.sub_chunk = h->tun.get("OMC_SUB_CHUNK") ? atoi(h->tun.get("OMC_SUB_CHUNK")) : 3;
+    w.sub_lazy = h->tun.get("OMC_SUB_LAZY") ? atoi(h->tun.get("OMC_SUB_LAZY")) : 1;
+    w.sub_tol = h->tun.get("OMC_SUB_TOL") ? atof(h->tun.get("OMC_SUB_TOL")) : 1e-10;
+    w.sub_adapt = h->tun.get("OMC_SUB_ADAPT") ? atof(h->tun.get("OMC_SUB_ADAPT")) : 1e-3;
+    w.sub_debug = h->tun.get("OMC_SUB_DEBUG") ? atoi(h->tun.get("OMC_SUB_DEBUG")) : 0;
     w.sub_enable = 0;     // decided below, once the cone kernel variant is known
     ENS(h->bXsC, sB * w.np16 * 16 * 8); ENS(h->bsubSC, sB * 18 * 8); ENS(h->bsubIC, sB * 3 * sizeof(int));
     HIPCHK(hipMemsetAsync(h->bXsC.p, 0, sB * w.np16 * 16 * 8, h->stream));
@@ -509,7 +561,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.sub_onC = h->bsubIC.as<int>(); w.confirm = h->bsubIC.as<int>() + sB; w.sep_done = nullptr;
     w.cert_enable = 0;
   }
-  if (!getenv("OMC_COLD_CHECK")) {   // warm-started eigenvalues for the certificate matrix
+  if (!h->tun.get("OMC_COLD_CHECK")) {   // warm-started eigenvalues for the certificate matrix
     ENS(h->bMbufC, sB * w.np16 * w.np16 * 8); ENS(h->bVrowC, sB * w.np16 * w.np16 * 8); ENS(h->bchkS, sB * 8); ENS(h->bchkI, sB * sizeof(int));
     HIPCHK(hipMemsetAsync(h->bMbufC.p, 0, sB * w.np16 * w.np16 * 8, h->stream));
     HIPCHK(hipMemsetAsync(h->bVrowC.p, 0, sB * w.np16 * w.np16 * 8, h->stream));   // its zero padding feeds the branch-free K loop of the MFMA GEMM: 0 x garbage could be NaN
@@ -610,7 +662,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   {
     const int c_lds = std::min(h->cmax, 64);
     w.cp_lds_c = c_lds;
-    w.cp_keepB = (c_lds <= 40 || getenv("OMC_COLPROX_KEEPB")) ? 1 : 0;
+    w.cp_keepB = (c_lds <= 40 || h->tun.get("OMC_COLPROX_KEEPB")) ? 1 : 0;
     w.cp_lds_doubles = w.cp_keepB ? c_lds * c_lds + 5 * c_lds + 8 : c_lds * (c_lds + 1) / 2 + 4 * c_lds + 8;
     if ((size_t)4 * w.cp_lds_doubles * 8 > OMC_MAX_DYN_LDS) { w.cp_lds_c = 48; w.cp_lds_doubles = 48 * 48 + 5 * 48 + 8; w.cp_keepB = 1; }
     if (h->cmax > w.cp_lds_c) {
@@ -642,16 +694,16 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
           w.cone_scratch = h->bcone.as<double>();
         }
       }
-      h->ws_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;   // WS_JROWS
+      h->ws_lpp = (rpl <= 32 && h->tun.get("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;   // WS_JROWS
       // subspace tracking needs the warm-started kernel as its seed / fall-back and at least 3 x 16 rows
-      w.sub_enable = (h->ws_lpp && n >= 48 && omc_cone_sub_lds(w.np16) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE")) ? 1 : 0;
+      w.sub_enable = (h->ws_lpp && n >= 48 && omc_cone_sub_lds(w.np16) <= OMC_MAX_DYN_LDS && !h->tun.get("OMC_NO_SUBSPACE")) ? 1 : 0;
       w.sub_zscratch = nullptr;
       if (w.sub_enable && w.np16 > 512) { ENS(h->bsubz, sB * 16 * (size_t)(w.np16 + 2) * 8); w.sub_zscratch = h->bsubz.as<double>(); }
-      w.cert_enable = (w.sub_enable && w.MbufC && (getenv("OMC_CERT_SUB") || w.np16 > 512)) ? 1 : 0;      // large orders: the certificate eigenvalues by the tracked block too (rigorous confirmation before anything is reported)
-      w.sep_done = (w.sub_enable && !getenv("OMC_NO_SEP_SUB")) ? h->bsubIC.as<int>() + 2 * sB : nullptr;   // opt-in: measured no gain (the eigenvalues are not what the check spends its time on) and fewer rigorous samples of the bound
+      w.cert_enable = (w.sub_enable && w.MbufC && (h->tun.get("OMC_CERT_SUB") || w.np16 > 512)) ? 1 : 0;      // large orders: the certificate eigenvalues by the tracked block too (rigorous confirmation before anything is reported)
+      w.sep_done = (w.sub_enable && !h->tun.get("OMC_NO_SEP_SUB")) ? h->bsubIC.as<int>() + 2 * sB : nullptr;   // opt-in: measured no gain (the eigenvalues are not what the check spends its time on) and fewer rigorous samples of the bound
     }
     h->glob_lds = ((size_t)n * (n + 1) / 2 + (size_t)n * k + (size_t)rmax * k + 3 * Rmax + 8 + 16 * (size_t)n) * 8 + 16;   // packed lower triangle of the target; 16 = GL_XS staged cut vectors
-    h->glob_use_lds = (h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS) && !getenv("OMC_GLOBAL_NOLDS");   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
+    h->glob_use_lds = (h->glob_lds + 20 * 1024 <= OMC_MAX_DYN_LDS) && !h->tun.get("OMC_GLOBAL_NOLDS");   // + the static LDS of k_global (NNQP scratch for NNQP_PMAX = 64 passive rows)
     if (!h->glob_use_lds) {
       w.glob_scratch_stride = h->glob_lds / 8 + 8;
       ENS(h->bglob, sB * w.glob_scratch_stride * 8);
@@ -757,8 +809,8 @@ int omc_relax_solve(omc_instance* h) {
   // OMC_STREAMS=1 serialises everything on one stream (kernel-by-kernel measurements).  OMC_GROUPS=2 additionally splits
   // the slots in two groups with their own stream triple, meeting only at the certificate checks, so that one group's
   // global step overlaps the other's cone kernel: measured slower (219/s), kept for experiments only.
-  const bool multi = !(getenv("OMC_STREAMS") && atoi(getenv("OMC_STREAMS")) <= 1);
-  const int G = (multi && S >= 64 && getenv("OMC_GROUPS") && atoi(getenv("OMC_GROUPS")) == 2) ? 2 : 1;
+  const bool multi = !(h->tun.get("OMC_STREAMS") && atoi(h->tun.get("OMC_STREAMS")) <= 1);
+  const int G = (multi && S >= 64 && h->tun.get("OMC_GROUPS") && atoi(h->tun.get("OMC_GROUPS")) == 2) ? 2 : 1;
   if (multi && !h->ev_main) {
     for (int g = 0; g < 2; ++g) {
       for (int q = 0; q < 4; ++q) HIPCHK(hipStreamCreateWithFlags(&h->gs[g][q], hipStreamNonBlocking));
@@ -769,11 +821,11 @@ int omc_relax_solve(omc_instance* h) {
   // compact list of the slots that hold a running node: the per-iteration kernels launch over it (rebuilt when slots finish or are refilled)
   std::vector<char> parked(S, 0);      // finished, waiting for the next harvest
   int check_index = 0;
-  const int refill_every = std::max(1, getenv("OMC_REFILL_EVERY") ? atoi(getenv("OMC_REFILL_EVERY")) : 3);
+  const int refill_every = std::max(1, h->tun.get("OMC_REFILL_EVERY") ? atoi(h->tun.get("OMC_REFILL_EVERY")) : 3);
   std::vector<int> alist(S);
   for (int b = 0; b < S; ++b) alist[b] = b;
   int nlist = S;
-  const bool use_list = !(getenv("OMC_NO_SLOT_LIST"));
+  const bool use_list = !(h->tun.get("OMC_NO_SLOT_LIST"));
   auto push_list = [&]() -> int {
     nlist = 0;
     for (int b = 0; b < S; ++b) if (node_of[b] >= 0 && !parked[b]) alist[nlist++] = b;
@@ -791,9 +843,9 @@ int omc_relax_solve(omc_instance* h) {
   // the body of an iteration (fork, three concurrent blocks, join, global step) is captured once into a hipGraph and replayed; it is
   // captured again only when the number of live slots changes.  Per-kernel HIP-event timing is not available inside a graph, so the
   // large batches that the bench times keep the eager path.
-  const int graph_max = getenv("OMC_GRAPH_MAX") ? atoi(getenv("OMC_GRAPH_MAX")) : 16;      // measured: -6 % per iteration at batch 1, +8 % at 128 slots of order 200
-  const bool no_graph = getenv("OMC_NO_GRAPH") != nullptr;      // read once per solve, not per iteration
-  const int timing_stride = getenv("OMC_TIMING_STRIDE") ? atoi(getenv("OMC_TIMING_STRIDE")) : 1;
+  const int graph_max = h->tun.get("OMC_GRAPH_MAX") ? atoi(h->tun.get("OMC_GRAPH_MAX")) : 16;      // measured: -6 % per iteration at batch 1, +8 % at 128 slots of order 200
+  const bool no_graph = h->tun.get("OMC_NO_GRAPH") != nullptr;      // read once per solve, not per iteration
+  const int timing_stride = h->tun.get("OMC_TIMING_STRIDE") ? atoi(h->tun.get("OMC_TIMING_STRIDE")) : 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr}; int gexec_n = -1;
   struct GraphGuard { hipGraphExec_t* e; ~GraphGuard() { for (int q = 0; q < 2; ++q) if (e[q]) (void)hipGraphExecDestroy(e[q]); } } gguard{gexec};
   auto body = [&](int g, const OmcWS& wg, bool timed, bool with_aa) -> int {
@@ -805,7 +857,7 @@ int omc_relax_solve(omc_instance* h) {
 #define MAYBE_TIMED(strm, cls, units_, call) do { if (timed) TIMED_ON(strm, cls, units_, call); else { call; } } while (0)
     // the cone workgroups are few (two per CU, long serial phases) and the column waves many: the cone kernel goes first so that its
     // workgroups are resident when the column kernel floods the wave slots (OMC_COLPROX_FIRST=1 restores the other order)
-    static const bool colprox_first = getenv("OMC_COLPROX_FIRST") != nullptr;
+    const bool colprox_first = h->tun.get("OMC_COLPROX_FIRST") != nullptr;
     if (shor) {
       // Shor mode: clip on the main stream, the order-(n+m) cone on the second, small cone + order-5 blocks on the third; then the
       // global step: rows / Y (base kernel), columns (X, W, Theta, duals of the big cone), duals of the order-5 blocks, per-slot sums
@@ -830,7 +882,7 @@ int omc_relax_solve(omc_instance* h) {
     // The full eigen-kernel runs the slots that have no tracked block (or are backing off) -- a handful per launch, each a long single-workgroup
     // job, known before the iteration starts (ws_first) -- on a stream of its own beside k_cone_sub; what k_cone_sub then could not do (a failed
     // call, ~1 in 30 000) is a second, almost empty launch behind both.  One launch after k_cone_sub made every iteration wait for the sum.
-    static const bool ws_split_ok = getenv("OMC_NO_WS_SPLIT") == nullptr;
+    const bool ws_split_ok = h->tun.get("OMC_NO_WS_SPLIT") == nullptr;
     const bool split = multi && ws_split_ok && w.sub_enable && h->ws_lpp && w.ws_first;
     if (split) {      // on the small-cone stream, behind k_small (a fifth stream would share a hardware queue with one of the other four: measured, k_small then ran behind it)
       MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
@@ -1014,7 +1066,7 @@ int omc_relax_solve(omc_instance* h) {
     HIPCHK(hipStreamSynchronize(s));
     for (int q = 0; q < 8; ++q) h->big_sub_tot[q] = 0;
     for (int b = 0; b < S; ++b) for (int q = 0; q < 8; ++q) h->big_sub_tot[q] += ss[8 * b + q];
-    if (getenv("OMC_SHOR_DEBUG")) for (int b = 0; b < S && b < 4; ++b) fprintf(stderr, "slot %d big-cone subspace: calls %d steps %d fallbacks %d seeds %d\n", b, ss[8 * b], ss[8 * b + 1], ss[8 * b + 2], ss[8 * b + 3]);
+    if (h->tun.get("OMC_SHOR_DEBUG")) for (int b = 0; b < S && b < 4; ++b) fprintf(stderr, "slot %d big-cone subspace: calls %d steps %d fallbacks %d seeds %d\n", b, ss[8 * b], ss[8 * b + 1], ss[8 * b + 2], ss[8 * b + 3]);
     HIPCHK(hipMemsetAsync(h->wbig.sub_stat, 0, sizeof(int) * ss.size(), s));
   }
   HIPCHK(hipGetLastError());
@@ -1256,7 +1308,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   if (h->k > 1) {
     bool all_free = true;
     for (int g = 0; g < NG && all_free; ++g) for (int j = 0; j < m; ++j) if (gh[g].ctype[j] != 0) { all_free = false; break; }
-    if (all_free && !getenv("OMC_SHOR_EXPLICIT")) {
+    if (all_free && !h->tun.get("OMC_SHOR_EXPLICIT")) {
       int rc0 = omc_relax_stage(h, B, params, cut_type, L, cut_x, cut_Uhat, cut_dir, U_lower, U_upper);
       if (rc0) return rc0;
       h->shor_via_base = true;
@@ -1367,7 +1419,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
       if (rpl > 32 && N <= 1024) { lpp = 64; rpl = (((N + 63) / 64) + 1) & ~1; Nrp = rpl * 64; ldw = Nrp + 2; wb.ws_ld = ldw; }
       need = ((size_t)Np2 * ldw + 3 * Np2) * 8 + (size_t)(Np2 + 2) * 4 + 64;
     }
-    h->big_lpp = (rpl <= 32 && getenv("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
+    h->big_lpp = (rpl <= 32 && h->tun.get("OMC_NO_WARMSTART") == nullptr) ? lpp : 0;
     // generic cold kernel (orders beyond the warm-started one): Np x (Np | 1) matrix + 2 Np doubles + Np ints
     const int ldc = Np2 | 1;
     h->big_cone_lds = ((size_t)Np2 * ldc + 2 * Np2) * 8 + (size_t)Np2 * 4 + 16;
@@ -1382,7 +1434,7 @@ int omc_relax_stage_shor(omc_instance* h, int B, const omc_relax_params* params,
   // the big cone's input has a handful of positive eigenvalues once the iterate has settled (measured: 2 - 5 of n + m): the tracked-subspace
   // kernel of the base engine follows them; the warm-started full kernel seeds the block and is the fall-back
   wb.trM = sh.trB;
-  if (h->big_lpp && N >= 48 && omc_cone_sub_lds(NPb) <= OMC_MAX_DYN_LDS && !getenv("OMC_NO_SUBSPACE") && !getenv("OMC_SHOR_NO_SUBSPACE")) {
+  if (h->big_lpp && N >= 48 && omc_cone_sub_lds(NPb) <= OMC_MAX_DYN_LDS && !h->tun.get("OMC_NO_SUBSPACE") && !h->tun.get("OMC_SHOR_NO_SUBSPACE")) {
     ENS(h->sXsB, sB * NPb * 16 * 8); ENS(h->ssubSB, sB * 16 * 8); ENS(h->ssubIB, sB * 12 * sizeof(int));
     HIPCHK(hipMemsetAsync(h->sXsB.p, 0, sB * NPb * 16 * 8, s));
     HIPCHK(hipMemsetAsync(h->ssubSB.p, 0, sB * 16 * 8, s));
@@ -1608,7 +1660,7 @@ int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q
                               : ((size_t)4 * n * k + (size_t)2 * n * k * k + (size_t)k * m + 2 * Rmax + 8) * 8;
   w.scratch = nullptr; w.scratch_stride = 0;
   size_t lds_launch = lds;
-  if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS - 8 * 1024 : (size_t)128 * 1024) || getenv("OMC_ALTMIN_NOLDS")) {
+  if (lds + 8 * 1024 > ((k == 1) ? (size_t)OMC_MAX_DYN_LDS - 8 * 1024 : (size_t)128 * 1024) || h->tun.get("OMC_ALTMIN_NOLDS")) {
     // the problem does not fit the LDS (config 5: 1000 x 1000, k = 2 needs 144 KB): the same kernel runs on a per-problem global slab
     w.scratch_stride = lds / 8 + 8;
     ENS(h->aG2, (size_t)B * w.scratch_stride * 8);
@@ -1851,9 +1903,24 @@ int omc_debug_residuals(omc_instance* h, double* rp, double* rd) {
   return 0;
 }
 
+int omc_tuning_set(omc_instance* h, const char* name, const char* value) {
+  if (!h || !name) return fail(OMC_ERR_ARGUMENT, "omc_tuning_set: handle or name is NULL");
+  bool known = false;
+  for (const char* key : OMC_TUNING_KEYS) if (!strcmp(key, name)) known = true;
+  if (!known) return fail(OMC_ERR_ARGUMENT, "omc_tuning_set: unknown knob");
+  if (value) h->tun.kv[name] = value; else h->tun.kv.erase(name);
+  return 0;
+}
+
+int omc_tuning_reload_env(omc_instance* h) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  tuning_from_env(h->tun);
+  return 0;
+}
+
 int omc_debug_stamps(omc_instance* h, double* out32) {
   if (!h || !out32 || !h->ws.stamps) return fail(OMC_ERR_ARGUMENT, "no stamps");
-  if (getenv("OMC_SUB_DEBUG") && atoi(getenv("OMC_SUB_DEBUG")) == 3 && h->ws.B >= 8) {      // diagnostics: three histograms (tools/diagnostics/gpu_nkeep_hist.py passes 96 doubles)
+  if (h->tun.get("OMC_SUB_DEBUG") && atoi(h->tun.get("OMC_SUB_DEBUG")) == 3 && h->ws.B >= 8) {      // diagnostics: three histograms (tools/diagnostics/gpu_nkeep_hist.py passes 96 doubles)
     HIPCHK(hipMemcpy(out32, h->ws.stamps, 96 * 8, hipMemcpyDeviceToHost));
     return 0;
   }

@@ -2937,8 +2937,8 @@ void omc_launch_cone_ws(const OmcWS* w, int lpp, int use_lds, size_t lds_bytes, 
     if (lpp == 64) {      // orders 513 .. 1024: a whole wave per column pair (16 rows per lane), G in global scratch
       if (rpl2 == 8) hipLaunchKernelGGL((k_cone_ws<64, false, 8, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
       else hipLaunchKernelGGL((k_cone_ws<64, false, 0, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
-    } else if (rpl2 == 7 && !getenv("OMC_CONE_512")) hipLaunchKernelGGL((k_cone_ws<16, false, 7, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
-    else if (rpl2 == 8 && !getenv("OMC_CONE_512")) hipLaunchKernelGGL((k_cone_ws<16, false, 8, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
+    } else if (rpl2 == 7 && !w->cone_512) hipLaunchKernelGGL((k_cone_ws<16, false, 7, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
+    else if (rpl2 == 8 && !w->cone_512) hipLaunchKernelGGL((k_cone_ws<16, false, 8, 1024>), dim3(w->nB), dim3(1024), 0, s, *w);
     else hipLaunchKernelGGL((k_cone_ws<16, false, 0>), dim3(w->nB), dim3(512), 0, s, *w);
   }
 }

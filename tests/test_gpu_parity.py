@@ -316,12 +316,12 @@ def test_large_order_uses_l2_resident_path(have_gpu, omc, orc):
     assert g["iters"] == r["iters"] and g["status_code"] == r["termination_status"]
     assert g["objective"] == pytest.approx(r["objective"], rel=OBJ_REL)
     assert g["dual_bound"] == pytest.approx(r["dual_bound"], rel=1e-5)
-    os.environ["OMC_GLOBAL_NOLDS"] = "1"            # the same solve with the target of k_global in its L2-resident scratch
+    eng.tuning_set("OMC_GLOBAL_NOLDS", "1")         # the same solve with the target of k_global in its L2-resident scratch
     try:
         g2 = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P)[0]
         assert not eng.solver_info()["global_lds"]
     finally:
-        del os.environ["OMC_GLOBAL_NOLDS"]
+        eng.tuning_set("OMC_GLOBAL_NOLDS", None)
     assert g2["iters"] == g["iters"] and g2["status_code"] == g["status_code"]
     assert g2["objective"] == pytest.approx(g["objective"], rel=1e-10) and g2["dual_bound"] == pytest.approx(g["dual_bound"], rel=1e-8)
     eng.close()
@@ -519,11 +519,11 @@ def test_order_200_l2_resident_variants_agree(have_gpu, omc):
     eng = omc.Engine(A, mask, gamma, c["k"])
     P = omc.default_params(rho_scale=4.0, max_iters=125)
     a = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P, want_X=False)[0]
-    os.environ["OMC_CONE_512"] = "1"
+    eng.tuning_set("OMC_CONE_512", "1")
     try:
         b = eng.matrix_completion_SDP_relaxation([[]], "linear", params=P, want_X=False)[0]
     finally:
-        del os.environ["OMC_CONE_512"]
+        eng.tuning_set("OMC_CONE_512", None)
     assert a["iters"] == b["iters"] and a["status_code"] == b["status_code"]
     assert a["objective"] == pytest.approx(b["objective"], rel=1e-10) and a["dual_bound"] == pytest.approx(b["dual_bound"], rel=1e-8)
     assert a["dual_bound"] <= a["objective"] * (1 + 1e-6)
@@ -989,11 +989,11 @@ def test_altmin_global_slab_variant(have_gpu, omc, orc):
         dirs = orc.child_directions("linear", k)
         nodes = [[], [(x, U0 * 0.7, list(dirs[0]))]]
         a = eng.alternating_minimization([U0, U0], nodes, "linear", max_iters=30)
-        os.environ["OMC_ALTMIN_NOLDS"] = "1"
+        eng.tuning_set("OMC_ALTMIN_NOLDS", "1")
         try:
             b = eng.alternating_minimization([U0, U0], nodes, "linear", max_iters=30)
         finally:
-            del os.environ["OMC_ALTMIN_NOLDS"]
+            eng.tuning_set("OMC_ALTMIN_NOLDS", None)
         for g, h in zip(a, b):
             assert g["n_iters"] == h["n_iters"] and np.array_equal(g["objectives"], h["objectives"])
             assert np.array_equal(g["U"], h["U"]) and np.array_equal(g["V"], h["V"])
@@ -1040,16 +1040,14 @@ def test_config5_node_evaluation(have_gpu, omc, orc):
 
 
 def _env_run(eng, omc, nodes, P, env):
-    old = {k_: os.environ.get(k_) for k_ in env}
-    os.environ.update(env)
+    """One relaxation of `nodes` with the tuning knobs `env` set on the instance (omc_tuning_set: the library reads no environment after creation)."""
+    for k_, v in env.items():
+        eng.tuning_set(k_, v)
     try:
         return eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_X=False)
     finally:
-        for k_, v in old.items():
-            if v is None:
-                del os.environ[k_]
-            else:
-                os.environ[k_] = v
+        for k_ in env:
+            eng.tuning_set(k_, None)
 
 
 def test_colprox_pair_kernel_against_one_column_kernel(have_gpu, omc, orc):
@@ -1098,6 +1096,14 @@ def test_split_launch_of_the_full_eigen_kernel_is_bit_identical(have_gpu, omc):
     a = _env_run(eng, omc, nodes, P, {})
     b = _env_run(eng, omc, nodes, P, {"OMC_NO_WS_SPLIT": "1"})
     c_ = _env_run(eng, omc, nodes, P, {"OMC_TIMING_STRIDE": "8"})
+    with pytest.raises(omc.OmcError):
+        eng.tuning_set("OMC_NOT_A_KNOB", "1")                            # unknown knobs are refused, not ignored
+    os.environ["OMC_NO_WS_SPLIT"] = "1"                                  # the environment is read at creation (and on request) only
+    try:
+        d_ = eng.matrix_completion_SDP_relaxation(nodes[:4], "linear", params=P, want_X=False)
+    finally:
+        del os.environ["OMC_NO_WS_SPLIT"]
+    assert [o["iters"] for o in d_] == [o["iters"] for o in a[:4]]
     for x, y, z in zip(a, b, c_):
         for key in ("objective", "dual_bound", "iters", "status_code"):
             assert x[key] == y[key] == z[key], key

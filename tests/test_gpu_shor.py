@@ -279,13 +279,12 @@ def test_rank2_shor_form_value_and_full_constraint_set(have_gpu, omc, orc, sh):
     assert orc.compute_SDP_relaxation_objective(r["X"], r["Theta"], A, mask, GAMMA, W=r["W"]) == pytest.approx(r["objective"], rel=1e-9)
     # every column of this instance has an unobserved entry, so the call above was served by the base engine (the program without minors IS the base
     # relaxation then); the explicit Shor path (order-(n+m) cone, column paraboloids) must give the same value and an equally feasible extension
-    import os
-    os.environ["OMC_SHOR_EXPLICIT"] = "1"
+    eng.tuning_set("OMC_SHOR_EXPLICIT", "1")
     try:
         r2 = eng.matrix_completion_SDP_relaxation([[]], "linear", omc.default_params(eps_gap=1e-6), add_Shor_valid_inequalities=True,
                                                   shor_info=[(minors, None)], want_Theta=True, want_V=True)[0]
     finally:
-        os.environ.pop("OMC_SHOR_EXPLICIT")
+        eng.tuning_set("OMC_SHOR_EXPLICIT", None)
     assert r2["status_code"] == 0 and r2["objective"] == pytest.approx(r["objective"], rel=3e-6)
     assert sh.shor_rank_k_residuals(2, st, r2["X"], r2["W"], r2)["max"] <= 1e-9
     assert r2["iters"] != r["iters"]                      # really another solver path
