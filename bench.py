@@ -357,8 +357,8 @@ def main():
         ach = work * projections / max(ms_ * 1e-3, 1e-12) / 1e12
         return dict(kernel=name, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, ms=round(ms_, 2), work_per_node_iteration=work)
     kernel_rooflines = [
-        kroof("k_colprox", ["colprox"], "mfma", f_frac, F64_PEAK_TFLOPS, "TFLOP/s"),
-        kroof("k_colprox (bytes)", ["colprox"], "hbm", b_frac, HBM_PEAK, "TB/s"),
+        kroof("k_colprox_pair (two columns per wave; k_colprox for columns above 32 rows)", ["colprox"], "mfma", f_frac, F64_PEAK_TFLOPS, "TFLOP/s"),
+        kroof("k_colprox_pair (bytes)", ["colprox"], "hbm", b_frac, HBM_PEAK, "TB/s"),
         kroof("cone block: k_cone_sub + k_cone_ws", ["cone", "cone_sub"], "mfma", f_proj(n), F64_PEAK_TFLOPS, "TFLOP/s"),
         kroof("k_global", ["global"], "hbm", b_glob, HBM_PEAK, "TB/s"),
         kroof("k_small", ["small"], "mfma", f_small, F64_PEAK_TFLOPS, "TFLOP/s"),

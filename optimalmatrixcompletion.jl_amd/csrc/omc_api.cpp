@@ -81,6 +81,7 @@ static const char* const OMC_TUNING_KEYS[] = {
   "OMC_NO_SUBSPACE",
   "OMC_NO_WARMSTART",
   "OMC_NO_WS_SPLIT",
+  "OMC_NO_YX",
   "OMC_REFILL_EVERY",
   "OMC_SHOR_DEBUG",
   "OMC_SHOR_EXPLICIT",
@@ -123,7 +124,7 @@ struct omc_instance {
   DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY, dsolo;
   int nsolo = 0;      // columns that k_colprox_pair leaves to k_colprox (more than 32 observed rows, unpaired last column)
   // batch workspace
-  DevBuf bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
+  DevBuf bYx, bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
   DevBuf bR, brkind, brcut, brbi, brbj, brcoef, brrhs, bcutx, bG, blam;
   DevBuf bobjcol, baaF, baaG, baaZ, baaS, baaI, bMbufC, bVrowC, bchkS, bchkI;
   DevBuf bslotlist, bgap, bvotes, blamDX, bXsC, bsubSC, bsubIC;
@@ -278,7 +279,7 @@ void omc_instance_destroy(omc_instance* h) {
   (void)hipSetDevice(h->device);
   (void)omc_comm_destroy(h);
   h->bcomm.release(); h->amobj.release();
-  DevBuf* all[] = {&h->dsolo, &h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
+  DevBuf* all[] = {&h->bYx, &h->dsolo, &h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
@@ -569,6 +570,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     w.MbufC = h->bMbufC.as<double>(); w.VrowC = h->bVrowC.as<double>(); w.fro2c = h->bchkS.as<double>(); w.vvalidC = h->bchkI.as<int>();
   }
   w.Y = h->bY.as<double>(); w.Yp = h->bYp.as<double>(); w.U = h->bU.as<double>();
+  w.Yx = nullptr;
+  if (!shor && !P.accel && !h->tun.get("OMC_NO_YX")) { ENS(h->bYx, sB * n * n * 8); w.Yx = h->bYx.as<double>(); }      // 2 Y - Yp for the column gathers (k_aa rewrites Y and Yp behind k_global's back)
   w.D1 = h->bD1.as<double>(); w.D3 = h->bD3.as<double>(); w.W1 = h->bW1.as<double>(); w.E3 = h->bE3.as<double>();
   w.dS = h->bdS.as<double>();
   {

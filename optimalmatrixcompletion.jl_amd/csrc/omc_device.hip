@@ -85,7 +85,7 @@ __global__ void k_setup(OmcWS w) {
     for (int e = tid; e < n * n; e += T) {
       const int i = e % n, j = e / n;
       const double y = w.pY[(size_t)lf * n * n + e], d1 = w.pD1[(size_t)lf * n * n + e] * fw;
-      Y[e] = y; Yp[e] = y;
+      Y[e] = y; Yp[e] = y; if (w.Yx) w.Yx[(size_t)b * n * n + e] = y;
       w.D1[(size_t)b * n * n + e] = d1; w.D3[(size_t)b * n * n + e] = w.pD3[(size_t)lf * n * n + e] * fw; w.E3[(size_t)b * n * n + e] = 0.0;
       const double mv = y - d1;
       w.Mbuf[(size_t)b * NP * NP + (size_t)j * NP + i] = mv; fr2 += mv * mv; if (i == j) tr1 += mv;
@@ -123,7 +123,7 @@ __global__ void k_setup(OmcWS w) {
   for (int e = tid; e < n * n; e += T) {
     int i = e % n, j = e / n;
     double v = (i == j) ? d0 : 0.0;
-    Y[e] = v; Yp[e] = v;
+    Y[e] = v; Yp[e] = v; if (w.Yx) w.Yx[(size_t)b * n * n + e] = v;
     w.D1[(size_t)b * n * n + e] = 0.0; w.D3[(size_t)b * n * n + e] = 0.0; w.E3[(size_t)b * n * n + e] = 0.0;
   }
   {
@@ -226,7 +226,7 @@ __device__ __forceinline__ void colprox_body(const OmcWS& w, int mode, int b, in
     int p = e / c, q = e - p * c;
     if (q > p) continue;
     size_t a = (size_t)idx[q] * n + idx[p];
-    double yv = (mode == 0) ? (2.0 * Y[a] - Yp[a]) : Y[a];
+    double yv = (mode == 0) ? (w.Yx ? w.Yx[(size_t)b * n * n + a] : (2.0 * Y[a] - Yp[a])) : Y[a];
     double v = g * (yv - coef * vo[p] * vo[q]);
     if (p == q) v += 1.0;
     Bm[TRI(p, q)] = v;
@@ -341,6 +341,7 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
   const double gm = w.gamma;
   const double* Y = w.Y + (size_t)b * n * n;
   const double* Yp = w.Yp + (size_t)b * n * n;
+  const double* Yx = w.Yx ? w.Yx + (size_t)b * n * n : nullptr;
   double* alpha = ((mode == 0) ? w.alpha : w.alphaX) + (size_t)b * w.nnz + off;
   WSTAMP_BEGIN();
   const double a_reg = (lane < c) ? w.col_val[off + lane] : 0.0;
@@ -363,13 +364,13 @@ __device__ __forceinline__ void colprox_reg(const OmcWS& w, int mode, int b, int
         while (tri_i(ri + 1, 0) <= ec) ++ri;
         rr[u] = ri; qq[u] = ec - tri_i(ri, 0);
         const size_t a = (size_t)sidx[qq[u]] * n + sidx[ri];
-        y1[u] = Y[a];
-        y2[u] = (mode == 0) ? Yp[a] : 0.0;
+        y1[u] = (mode == 0 && Yx) ? Yx[a] : Y[a];
+        y2[u] = (mode == 0 && !Yx) ? Yp[a] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (vv[u]) {
-          const double yv = (mode == 0) ? (2.0 * y1[u] - y2[u]) : y1[u];
+          const double yv = (mode == 0 && !Yx) ? (2.0 * y1[u] - y2[u]) : y1[u];
           double v = gm * (yv - coef * vo[rr[u]] * vo[qq[u]]);
           if (rr[u] == qq[u]) v += 1.0 + diag_shift;
           dst[e0 + u * WAVE] = v;
@@ -530,6 +531,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
   const double gm = w.gamma;
   const double* Y = w.Y + (size_t)b * n * n;
   const double* Yp = w.Yp + (size_t)b * n * n;
+  const double* Yx = w.Yx ? w.Yx + (size_t)b * n * n : nullptr;      // 2 Y - Yp, one load per entry
   double* alpha = w.alpha + (size_t)b * w.nnz + off;
   const double a_reg = act ? w.col_val[off + l] : 0.0;
   const int my = act ? w.col_idx[off + l] : 0;
@@ -551,12 +553,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k
           const int iq = sidx[hb + qb + u];
           vq[u] = vo_s[hb + qb + u];
           const size_t a = (l > qb + u) ? (size_t)iq * n + my : (size_t)my * n + iq;
-          y1[u] = Y[a]; y2[u] = Yp[a];
+          y1[u] = Yx ? Yx[a] : Y[a]; y2[u] = Yx ? 0.0 : Yp[a];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int q = qb + u;
-          const double v = gm * ((2.0 * y1[u] - y2[u]) - coef * vo_r * vq[u]);
+          const double v = gm * ((Yx ? y1[u] : 2.0 * y1[u] - y2[u]) - coef * vo_r * vq[u]);
           R[q] = (l == q) ? (act ? v + 1.0 : 1.0) + shift : ((act && q < c) ? v : 0.0);      // rows / columns beyond the column's size: identity
         }
       } else {
@@ -2433,6 +2435,7 @@ __global__ void __launch_bounds__(512) k_global(OmcWS w) {
     rp2 += (w1 - yn) * (w1 - yn) + (w3y - yn) * (w3y - yn);
     rd2 += (yn - yold) * (yn - yold);
     Yp[a1] = yold; Y[a1] = yn;
+    if (w.Yx) w.Yx[(size_t)b * n * n + a1] = 2.0 * yn - yold;      // the matrix the column prox of the next iteration gathers
   }
   STAMP(13);
   rp2 = block_sum(rp2, red);

@@ -33,13 +33,14 @@ if mode in ("stats", "stats-between"):
 else:
     title = sys.argv[4] if len(sys.argv) > 4 else ""
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
-    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0])); grid = {}
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0])); grid = {}; wgsum = defaultdict(lambda: defaultdict(int))
     for r in csv.DictReader(open(f)):
         a = acc[r["Kernel_Name"]][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"]); grid[r["Kernel_Name"]] = r["Grid_Size"]
+        wgsum[r["Kernel_Name"]][r["Counter_Name"]] += int(r["Grid_Size"]) // max(1, int(r.get("Workgroup_Size", 1) or 1))      # workgroups launched: one per live slot for the per-slot kernels
     with open(out, "w") as fo:
         fo.write(title + "\n")
         for k_, cs in sorted(acc.items()):
             if k_.startswith("__amd") or not any(v[1] for v in cs.values()): continue
             n_ = max(v[0] for v in cs.values())
-            line = "%s launches=%d last_grid=%s " % (short(k_), n_, grid[k_]) + " ".join("%s=%.4g" % (c, v[1] / v[0]) for c, v in sorted(cs.items()))
+            line = "%s launches=%d last_grid=%s workgroups_total=%d " % (short(k_), n_, grid[k_], max(wgsum[k_].values())) + " ".join("%s=%.4g" % (c, v[1] / v[0]) for c, v in sorted(cs.items()))
             fo.write(line + "\n"); print(line)
