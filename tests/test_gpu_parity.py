@@ -1109,3 +1109,26 @@ def test_split_launch_of_the_full_eigen_kernel_is_bit_identical(have_gpu, omc):
             assert x[key] == y[key] == z[key], key
         assert np.array_equal(x["Y"], y["Y"]) and np.array_equal(x["Y"], z["Y"])
     eng.close()
+
+
+def test_config4_root_certified(have_gpu, omc, orc):
+    """BASELINE config 4 (500 x 500, rank 2) root run to certification: the two-sided 1e-6 gap, and the returned (X, Y, Theta, U) checked
+    against every cone and row of the reference's program (OMC.jl:1554-1685) at the tolerance the small cases use -- the oracle's
+    primal_residuals on the GPU's point (the oracle's own solve would take hours at this size; the residual evaluation takes seconds)."""
+    A, mask, gamma, c = omc.pkg.data.config_instance(4, seed=0)
+    n, m = A.shape
+    eng = omc.Engine(A, mask, gamma, c["k"])
+    P = omc.default_params(rho_scale=4.0, max_iters=1500, breakpoints=2)
+    g = eng.matrix_completion_SDP_relaxation([[]], "linear3", params=P, want_Theta=True)[0]
+    assert_finite(g)
+    assert g["status_code"] == 0, (g["termination_status"], g["iters"], g["objective"], g["dual_bound"])
+    assert abs(g["objective"] - g["dual_bound"]) <= 1.01e-6 * max(1.0, abs(g["objective"]))
+    inst = orc.Instance(A, mask, gamma, c["k"])
+    rows = orc.build_rows(inst, [], "linear3")
+    Theta = 0.5 * (g["Theta"] + g["Theta"].T)
+    res = orc.primal_residuals(inst, rows, g["Y"], g["U"], g["X"], Theta)
+    assert res["max"] <= 2e-5 * max(1.0, np.abs(Theta).max()), res
+    assert orc.compute_SDP_relaxation_objective(g["X"], Theta, A, mask, gamma) == pytest.approx(g["objective"], rel=1e-8)
+    st = eng.subspace_stats()
+    assert st["fallbacks"] <= 10 and st["calls"] >= g["iters"] // 2, st
+    eng.close()
