@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("OMC_BENCH_PIPELINE", 1)), help="1: the K timed steps are K batches handed to the engine as one stream (continuous batching: "
                     "the slots a batch frees while its last nodes converge are refilled from the next batch, as a B&B queue that always holds open nodes would); "
                     "0: each step is staged, solved and drained on its own (rounds 1-2)")
+    ap.add_argument("--early-stop", type=float, default=None, help="early_stop_factor of the relaxation parameters (library default 1.5; 0 = rule off)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip latency_b1 / branching / time_to_gap / cpu_baseline (rank 0, N=1 only)")
     return ap.parse_args()
 
@@ -214,10 +215,10 @@ def main():
         if saved["key"] != (args.config, args.depth):
             sys.exit(f"bench.py: {cache} holds config/depth {saved['key']}")
         rho_scale, tune_log, nodes = saved["rho_scale"], saved["tune_log"], saved["nodes"]
-        P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel)
+        P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel, **({} if args.early_stop is None else {"early_stop_factor": args.early_stop}))
     else:
         rho_scale, tune_log = bnb.autotune_rho_scale(eng, cfg["cut_type"])
-        P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel)
+        P = omc_amd.default_params(rho_scale=rho_scale, slots=args.slots, accel=args.accel, **({} if args.early_stop is None else {"early_stop_factor": args.early_stop}))
         # every rank builds the same depth-d frontier (deterministic), keeps its round-robin share and expands THOSE subtrees until it
         # holds 2^d nodes again: distinct work per rank, identical amount of it
         nodes, _ = bnb.expand_frontier(eng, args.depth, cfg["cut_type"], params=P)
