@@ -75,6 +75,7 @@ static const char* const OMC_TUNING_KEYS[] = {
   "OMC_GROUPS",
   "OMC_JACOBI_TAU",
   "OMC_NO_COLPROX_PAIR",
+  "OMC_NO_COLPROX_WIDE",
   "OMC_NO_GRAPH",
   "OMC_NO_SEP_SUB",
   "OMC_NO_SLOT_LIST",
@@ -121,7 +122,8 @@ struct omc_instance {
   hipStream_t gs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t gev[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t ev_main = nullptr;
-  DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY, dsolo;
+  DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY, dsolo, dwide;
+  int nwide = 0;      // columns outside the pairs with at most 64 observed rows (k_colprox_wide)
   int nsolo = 0;      // columns that k_colprox_pair leaves to k_colprox (more than 32 observed rows, unpaired last column)
   // batch workspace
   DevBuf bYx, bY, bYp, bU, bD1, bD3, bW1, bE3, bQb, brr, bsm, bdS, balpha, balphaX, bsval, bMchk, bsmall, bchk;
@@ -241,15 +243,18 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   if ((rc = upload(h->dmask, h->mask.data(), (size_t)n * m, h->stream))) return rc;
   if ((rc = upload(h->dcol_ptr, h->col_ptr.data(), sizeof(int) * (m + 1), h->stream))) return rc;
   {
-    std::vector<int> solo;
+    std::vector<int> solo, wide;
+    const bool no_wide = h->tun.get("OMC_NO_COLPROX_WIDE") != nullptr;      // read at creation: the column lists are built here
+    auto place = [&](int j) { const int c = h->col_ptr[j + 1] - h->col_ptr[j]; if (c == 0) return; if (c <= 64 && !no_wide) wide.push_back(j); else solo.push_back(j); };
     for (int j0 = 0; j0 < m; j0 += 2) {
       const int j1 = j0 + 1;
       const int c0 = h->col_ptr[j0 + 1] - h->col_ptr[j0], c1 = (j1 < m) ? h->col_ptr[j1 + 1] - h->col_ptr[j1] : 0;
       if (j1 < m && c0 <= 32 && c1 <= 32) continue;
-      solo.push_back(j0); if (j1 < m) solo.push_back(j1);
+      place(j0); if (j1 < m) place(j1);
     }
-    h->nsolo = (int)solo.size();
+    h->nsolo = (int)solo.size(); h->nwide = (int)wide.size();
     if (h->nsolo && (rc = upload(h->dsolo, solo.data(), sizeof(int) * solo.size(), h->stream))) return rc;
+    if (h->nwide && (rc = upload(h->dwide, wide.data(), sizeof(int) * wide.size(), h->stream))) return rc;
   }
   if ((rc = upload(h->dcol_idx, h->col_idx.data(), sizeof(int) * h->nnz, h->stream))) return rc;
   if ((rc = upload(h->dcol_val, h->col_val.data(), sizeof(double) * h->nnz, h->stream))) return rc;
@@ -279,7 +284,7 @@ void omc_instance_destroy(omc_instance* h) {
   (void)hipSetDevice(h->device);
   (void)omc_comm_destroy(h);
   h->bcomm.release(); h->amobj.release();
-  DevBuf* all[] = {&h->bYx, &h->dsolo, &h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
+  DevBuf* all[] = {&h->dwide, &h->bYx, &h->dsolo, &h->dA, &h->dmask, &h->dcol_ptr, &h->dcol_idx, &h->dcol_val, &h->dNcnt, &h->dwY, &h->bY, &h->bYp, &h->bU,
                    &h->bD1, &h->bD3, &h->bW1, &h->bE3, &h->bQb, &h->brr, &h->bsm, &h->bdS, &h->bsmall, &h->bchk,
                    &h->balpha, &h->balphaX, &h->bsval, &h->bMchk,
                    &h->bR, &h->brkind, &h->brcut, &h->brbi, &h->brbj, &h->brcoef, &h->brrhs, &h->bcutx, &h->bG, &h->blam,
@@ -512,6 +517,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   if ((rc_ = upload(h->dwY, wY.data(), sizeof(double) * n * n, h->stream))) return rc_;
   w.col_ptr = h->dcol_ptr.as<int>(); w.col_idx = h->dcol_idx.as<int>(); w.col_val = h->dcol_val.as<double>();
   w.cp_pair = h->tun.get("OMC_NO_COLPROX_PAIR") ? 0 : 1; w.cone_512 = h->tun.get("OMC_CONE_512") ? 1 : 0; w.cp_series = h->tun.get("OMC_CP_SERIES") ? atoi(h->tun.get("OMC_CP_SERIES")) : 6; w.cp_maxpass = h->tun.get("OMC_CP_MAXPASS") ? atoi(h->tun.get("OMC_CP_MAXPASS")) : 60; w.cp_nsolo = h->nsolo; w.cp_solo = h->nsolo ? h->dsolo.as<int>() : nullptr;
+  w.cp_nwide = h->nwide; w.cp_wide = h->nwide ? h->dwide.as<int>() : nullptr;
   w.Ncnt = h->dNcnt.as<double>(); w.wY1 = h->dwY.as<double>();
   w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>();
 #define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)

@@ -120,6 +120,7 @@ struct OmcWS {
   // k_colprox_pair: two columns per wave (32 lanes each, matrix rows in registers) for the column pairs (2p, 2p + 1) whose columns hold at
   // most 32 observed rows each; the other columns (cp_solo, cp_nsolo of them) keep the one-column-per-wave kernel
   int cp_pair; int cp_nsolo; const int* cp_solo;
+  int cp_nwide; const int* cp_wide;      // columns outside the pairs with at most 64 observed rows: k_colprox_wide (one column per wave, same algorithm)
   double* Yx;                // B*n*n: 2 Y - Yp, written by k_global (and k_setup) for the column gathers of k_colprox* (one load per entry instead of two); NULL with acceleration or Shor mode
   int cone_512;              // diagnostics (OMC_CONE_512): the 512-thread form of the L2-resident eigen-kernel at orders 193..256
   int cp_series;             // Neumann-series order of k_colprox_pair's finish (6; 3 = the second-order finish of colprox_reg)
@@ -164,6 +165,7 @@ void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStrea
 void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,
                                double* out, hipStream_t s);
 int omc_set_max_lds(void);
+void omc_launch_colprox_sweep(const OmcWS* w, hipStream_t s);      /* omc_colprox.hip */
 #ifdef __cplusplus
 }
 #endif

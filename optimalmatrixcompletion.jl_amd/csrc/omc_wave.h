@@ -6,6 +6,9 @@
 
 #define WAVE 64
 
+// slot of the i-th workgroup of a launch over the compact list of live slots
+__device__ __forceinline__ int slot_of(const OmcWS& w, int i) { return w.slot_list ? w.slot_list[w.b0 + i] : w.b0 + i; }
+
 // ---------------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------------
