@@ -221,6 +221,9 @@ int omc_separation_batch(omc_instance* h, int B, int breakpoints, const double* 
 
 /* ---- rounding glue: svd(M).U[:,1:k] of the symmetric PSD Y (OMC.jl:873) -------------------------------- */
 int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded);
+/* svd(X).U[:, 1:k] for B matrices X (n x m, column-major): the rank-k rounding of an incumbent or of the zero-filled A
+ * (OMC.jl:524, 564, 921).  Gram product X X' on the matrix cores, then the k dominant eigenvectors; sign as omc_round_Y_batch. */
+int omc_left_singular_batch(omc_instance* h, int B, const double* X, double* U_out);
 
 /* ---- Shor minors ------------------------------------------------------------------------------------------
  * generate_rank1_matrix_completion_Shor_constraints_indexes (OMC.jl:2545-2612): the 2 x 2 minors (i1 < i2, j1 < j2) whose

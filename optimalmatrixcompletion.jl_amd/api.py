@@ -369,6 +369,16 @@ class Engine:
         _lib.check(self._lib.omc_round_Y_batch(self._h, B, _lib.ptr(Yb), _lib.ptr(U)))
         return [U[b].reshape((n, k), order="F") for b in range(B)]
 
+    def left_singular(self, Xs):
+        """svd(X).U[:, 1:k] of n x m matrices (OMC.jl:524, 564, 921), batched on the device (omc_left_singular_batch); sign: largest-magnitude entry positive."""
+        B, n, m, k = len(Xs), self.n, self.m, self.k
+        Xb = np.ascontiguousarray(np.stack([np.asfortranarray(x, dtype=np.float64).ravel(order="F") for x in Xs]))
+        if Xb.shape != (B, n * m):
+            raise ValueError("left_singular: every matrix must be n x m")
+        U = np.zeros((B, n * k))
+        _lib.check(self._lib.omc_left_singular_batch(self._h, B, _lib.ptr(Xb), _lib.ptr(U)))
+        return [U[b].reshape((n, k), order="F") for b in range(B)]
+
     def alternating_minimization(self, U_initials, nodes=None, disjunctive_cuts_type="linear", eps=1e-5, max_iters=100,
                                  time_limit=3600.0, reference_quirk_q1=True):
         """Batch form of OMC.jl:1979-2279 (use_disjunctive_cuts = true).  Returns dicts with the reference's keys

@@ -158,10 +158,18 @@ class Comm:
         return bool(t[0] > 0)
 
 
-def rank_k_projection(X, k):
+def left_singular(engine, X, k):
+    """svd(X).U[:, 1:k] (OMC.jl:524, 564, 921) on the device (omc_left_singular_batch: Gram product on the matrix cores + the eigen-kernel);
+    an engine without the entry point (a stub in the CPU tests) falls back to numpy."""
+    if engine is not None and hasattr(engine, "left_singular"):
+        return engine.left_singular([X])[0]
+    return np.linalg.svd(X, full_matrices=False)[0][:, :k]
+
+
+def rank_k_projection(X, k, engine=None):
     """X_k = U_k U_k' X with U_k = svd(X).U[:, 1:k] (OMC.jl:921): a matrix of rank <= k, so evaluate_objective(X_k) is a valid
     upper bound of the master problem whatever the relaxation's tolerances were."""
-    Uf = np.linalg.svd(X, full_matrices=False)[0][:, :k]
+    Uf = left_singular(engine, X, k)
     return Uf @ (Uf.T @ X), Uf
 
 
@@ -238,8 +246,7 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
     run_log = []
     # ---- root altmin (OMC.jl:521-621) ------------------------------------------------------------------------
     A0 = np.where(indices, A, 0.0)
-    Uf, _, _ = np.linalg.svd(A0, full_matrices=False)
-    U0 = Uf[:, :k]
+    U0 = left_singular(engine, A0, k)                                                      # OMC.jl:524
     solution = {}
     if altmin_flag:
         # OMC.jl:534-579: run 1 starts from the SVD of the zero-filled A, the others from it + sc * randn; all runs in ONE GPU
@@ -251,8 +258,7 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
         X0 = best["U"] @ best["V"]
     else:
         X0 = U0 @ (U0.T @ A0)
-    Us, _, _ = np.linalg.svd(X0, full_matrices=False)
-    U_init = Us[:, :k]
+    U_init = left_singular(engine, X0, k)                                                  # OMC.jl:564
     ub = float(engine.evaluate_objective(X0))
     from .data import compute_MSE
     mse0 = {kind: compute_MSE(X0, A, indices, kind) for kind in ("in", "out", "all")}                 # OMC.jl:570-572
@@ -408,7 +414,7 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                     if nid in local:
                         # the reference takes the relaxation value as the incumbent (OMC.jl:818-828); a first-order solve certifies that
                         # value only to eps_gap, so the incumbent is the master objective of the rank-k projection of X instead
-                        Xk, _ = rank_k_projection(local[nid]["X"], k)
+                        Xk, _ = rank_k_projection(local[nid]["X"], k, engine)
                         cand.append((float(engine.evaluate_objective(Xk)), Xk, "master"))
                     continue
                 split.append((nid, nd, row))
@@ -441,7 +447,7 @@ def branch_and_bound(engine, A, indices, *, node_selection="bestfirst", bestfirs
                 Xl = min(cand, key=lambda c: c[0])[1] if (cand and comm.rank == owner) else np.zeros((n, m))
                 Xl = comm.bcast_matrix(Xl, owner)
                 ub = g_ub
-                Ul = np.linalg.svd(Xl, full_matrices=False)[0][:, :k]                        # OMC.jl:921
+                Ul = left_singular(engine, Xl, k)                                            # OMC.jl:921
                 solution.update(objective=ub, X=Xl, U=Ul, Y=Ul @ Ul.T, objective_time_found=time.time() - start)
                 counters["nodes_master_feasible_improvement" if g_src == 0.0 else "nodes_relax_feasible_split_altmin_improvement"] += 1
             for nid, nd, row in split:                                                       # OMC.jl:951-989

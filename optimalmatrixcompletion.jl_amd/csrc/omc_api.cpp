@@ -1580,6 +1580,29 @@ int omc_round_Y_batch(omc_instance* h, int B, const double* Y, double* U_rounded
   return 0;
 }
 
+// svd(X).U[:, 1:k] of B matrices X (n x m): the k dominant eigenvectors of X X' (Gram product on the matrix cores, then the eigen-kernel of
+// omc_round_Y_batch); same canonical sign.  The singular values are well separated from zero for the matrices the driver rounds (products U V of
+// rank k, OMC.jl:564, 921; the zero-filled A of the root, OMC.jl:524), so squaring the condition number costs nothing that matters.
+int omc_left_singular_batch(omc_instance* h, int B, const double* X, double* U_out) {
+  if (!h || !X || !U_out) return fail(OMC_ERR_ARGUMENT, "NULL argument");
+  if (B <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
+  std::vector<int> L(B, 0);
+  omc_relax_params P = h->params; P.slots = B;
+  int rc = omc_relax_stage(h, B, &P, OMC_CUT_LINEAR, L.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  const OmcWS& w = h->ws;
+  const size_t n = h->n, m = h->m, k = h->k;
+  ENS(h->bXin, (size_t)B * n * m * 8);
+  HIPCHK(hipMemcpyAsync(h->bXin.p, X, 8 * (size_t)B * n * m, hipMemcpyHostToDevice, h->stream));
+  omc_launch_gram_XXt(&w, h->bXin.as<double>(), B, h->stream);
+  omc_launch_cone(&w, CONE_TOPK, h->cone_use_lds, h->cone_lds, h->stream);
+  HIPCHK(hipMemcpyAsync(U_out, w.U, 8 * (size_t)B * n * k, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  h->staged = false;
+  return 0;
+}
+
 int omc_altmin_batch(omc_instance* h, int B, int cut_type, int reference_quirk_q1, const int* L, const double* cut_x,
                      const double* cut_Uhat, const int8_t* cut_dir, const double* U_initial, double eps, int max_iters,
                      double time_limit, double* U, double* V, int* converged, int* n_iters, double* objectives,

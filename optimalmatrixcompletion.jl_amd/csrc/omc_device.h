@@ -165,6 +165,7 @@ void omc_launch_make_Theta(const OmcWS* w, const double* X, double* Th, hipStrea
 void omc_launch_eval_objective(int B, int n, int m, double gamma, const double* A, const uint8_t* mask, const double* X,
                                double* out, hipStream_t s);
 int omc_set_max_lds(void);
+void omc_launch_gram_XXt(const OmcWS* w, const double* X, int B, hipStream_t s);
 void omc_launch_colprox_sweep(const OmcWS* w, hipStream_t s);      /* omc_colprox.hip */
 #ifdef __cplusplus
 }

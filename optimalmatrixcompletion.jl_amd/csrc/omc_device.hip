@@ -2639,7 +2639,15 @@ static void launch_ws_lds(const OmcWS* w, int rpl2, size_t lds_bytes, hipStream_
     default: hipLaunchKernelGGL((k_cone_ws<LPP, true, 0>), dim3(w->nB), dim3(512), lds_bytes, s, *w); break;
   }
 }
+// Y[b] = X[b] X[b]' (both triangles) for B matrices X of size n x m (column-major), on the matrix cores: the Gram matrix whose k dominant eigenvectors
+// are svd(X).U[:, 1:k] (OMC.jl:524, 564, 921: the rank-k rounding of an incumbent)
+__global__ void __launch_bounds__(256) k_gram_XXt(OmcWS w, const double* X) {
+  const int b = blockIdx.x, n = w.n;
+  double* Y = w.Y + (size_t)b * n * n;
+  mfma_LLt(X + (size_t)b * n * w.m, n, w.m, [&](int i, int j, double v) { Y[(size_t)j * n + i] = v; Y[(size_t)i * n + j] = v; });
+}
 extern "C" {
+void omc_launch_gram_XXt(const OmcWS* w, const double* X, int B, hipStream_t s) { hipLaunchKernelGGL(k_gram_XXt, dim3(B), dim3(256), 0, s, *w, X); }
 void omc_launch_setup(const OmcWS* w, hipStream_t s) { hipLaunchKernelGGL(k_setup, dim3(w->B), dim3(256), 0, s, *w); }
 void omc_launch_colprox(const OmcWS* w, int mode, hipStream_t s) {
   const int wpb = 4;

@@ -1161,3 +1161,30 @@ def test_early_slow_progress_prediction_on_a_frontier_sample(have_gpu, omc):
     print(f"early SLOW_PROGRESS: {len(early)} of {len(nodes)} nodes; of {len(sample)} re-run without the rule {wrong} were certified before max_iters")
     assert wrong <= len(sample) // 2
     eng.close()
+
+
+def test_left_singular_vectors_on_the_device(have_gpu, omc, orc):
+    """omc_left_singular_batch = svd(X).U[:, 1:k] (OMC.jl:524, 564, 921): Gram product on the matrix cores + the top-k eigen-kernel, against
+    numpy's SVD for the matrices the driver rounds -- a rank-k product U V, the zero-filled A of the root, a relaxation's X -- at k = 1 and 2
+    (compared as projectors U U', and entry-wise after the canonical sign where the singular values are distinct)."""
+    for k in (1, 2):
+        A, mask = orc.make_instance(40, 52, k, seed=30 + k, kind="lowrank", n_indices=int(0.4 * 40 * 52))
+        eng = omc.Engine(A, mask, GAMMA, k)
+        rng = np.random.default_rng(k)
+        U = rng.standard_normal((40, k)); V = rng.standard_normal((k, 52))
+        root = eng.matrix_completion_SDP_relaxation([[]], "linear", params=omc.default_params(rho_scale=4.0))[0]
+        mats = [U @ V, np.where(mask, A, 0.0), root["X"]]
+        got = eng.left_singular(mats)
+        for X, g in zip(mats, got):
+            Uf, sv, _ = np.linalg.svd(X, full_matrices=False)
+            ref = Uf[:, :k]
+            assert np.allclose(g.T @ g, np.eye(k), atol=1e-10)
+            assert np.allclose(g @ g.T, ref @ ref.T, atol=1e-8 * max(1.0, sv[0] / max(sv[k - 1] - (sv[k] if len(sv) > k else 0.0), 1e-12)))
+            for j in range(k):
+                r = ref[:, j] * np.sign(ref[np.argmax(np.abs(ref[:, j])), j])
+                if k == 1 or abs(sv[0] - sv[1]) > 1e-6 * sv[0]:
+                    assert np.allclose(g[:, j], r, atol=1e-7)
+        # the driver's rounding goes through it
+        Xk, Uk = omc.pkg.bnb.rank_k_projection(root["X"], k, eng)
+        assert np.linalg.matrix_rank(Xk, tol=1e-9) <= k and np.allclose(Uk, got[2])
+        eng.close()
