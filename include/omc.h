@@ -155,6 +155,17 @@ int omc_relax_set_warm(omc_instance* h, int B, const int* load_from, const int* 
  * batch -- pop, prune (OMC.jl:1220-1244), build children -- while the device relaxes the current one.  One solve in flight per handle;
  * between submit and wait only omc_relax_poll may be called on the handle. */
 int omc_relax_submit(omc_instance* h);
+/* Appending nodes to a staged or RUNNING batch: the reference's loop pops from a queue that the children of relaxed nodes keep filling
+ * (OMC.jl:700-719, 2520-2542); a staged batch was closed until round 3.  omc_relax_reserve(h, extra_nodes, max_cuts) makes the NEXT
+ * omc_relax_stage size its per-node arrays for extra_nodes more nodes with at most max_cuts cuts each (default U bounds, same cut type and
+ * parameters as the staged batch).  omc_relax_append(h, B, L, cut_x, cut_Uhat, cut_dir, load_from, save_to) adds B nodes in the wire format of
+ * omc_relax_stage (load_from / save_to: warm-start pool entries as in omc_relax_set_warm, or NULL): before the solve starts, or while a
+ * submitted solve is running -- the loop hands them to free slots at its next check -- and is refused once that solve has ended (the end is
+ * decided under the same lock, so a node is either relaxed or refused, never lost).  Results: omc_relax_fetch returns every node, appended
+ * ones behind the staged ones in the order they were appended.  Not available in Shor mode. */
+int omc_relax_reserve(omc_instance* h, int extra_nodes, int max_cuts);
+int omc_relax_append(omc_instance* h, int B, const int* L, const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir,
+                     const int* load_from, const int* save_to);
 int omc_relax_poll(omc_instance* h, int* running, int* nodes_done, int* nodes_total);
 int omc_relax_wait(omc_instance* h);
 int omc_relax_fetch(omc_instance* h, double* objective, double* dual_bound, int* status, int* iters, double* Y,

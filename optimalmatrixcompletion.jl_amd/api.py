@@ -224,6 +224,23 @@ class Engine:
         _lib.check(self._lib.omc_relax_fetch_shor_V(self._h, _lib.ptr(V)))
         return [V[b].reshape(self._nqmax, 5) for b in range(self._B)]
 
+    def reserve(self, extra_nodes, max_cuts):
+        """Room for nodes appended to the NEXT staged batch (omc_relax_reserve): extra_nodes more nodes with at most max_cuts cuts each."""
+        _lib.check(self._lib.omc_relax_reserve(self._h, int(extra_nodes), int(max_cuts)))
+
+    def append(self, nodes, disjunctive_cuts_type="linear", load_from=None, save_to=None):
+        """Add nodes to the staged batch -- also while a submitted solve is running (omc_relax_append): the reference's queue keeps receiving
+        the children of relaxed nodes (OMC.jl:700-719, 2520-2542).  Raises OmcError once that solve has ended.  fetch() returns the appended
+        nodes behind the staged ones."""
+        n, k = self.n, self.k
+        L, cx, cU, cd = _pack_cuts(nodes, n, k, disjunctive_cuts_type)
+        lf = None if load_from is None else np.ascontiguousarray(np.asarray(load_from, dtype=np.int32))
+        sv = None if save_to is None else np.ascontiguousarray(np.asarray(save_to, dtype=np.int32))
+        if (lf is not None and lf.shape != (len(nodes),)) or (sv is not None and sv.shape != (len(nodes),)):
+            raise ValueError("load_from / save_to must hold one pool index per node")
+        _lib.check(self._lib.omc_relax_append(self._h, len(nodes), _lib.ptr(L), _lib.ptr(cx), _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(lf), _lib.ptr(sv)))
+        self._B += len(nodes)
+
     def solve(self):
         _lib.check(self._lib.omc_relax_solve(self._h))
 

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <mutex>
 
 #include "omc.h"
 #include "omc_device.h"
@@ -139,6 +140,9 @@ struct omc_instance {
   int cone_use_lds = 0, glob_use_lds = 0, small_use_lds = 0; size_t cone_lds = 0, glob_lds = 0, small_lds = 0;
   double last_solve_seconds = 0; long long total_sweeps = 0; int last_iters_total = 0;
   std::thread worker; std::atomic<int> worker_running{0}, nodes_done{0}; int worker_rc = 0; std::string worker_err;
+  // appending nodes to a staged / running batch (omc_relax_reserve, omc_relax_append): descriptor and output arrays are sized for node_cap nodes,
+  // the strides (rows, row-subspace columns, cuts per node) for reserve_cuts cuts; Btot_live is what the solve loop reads at its refill points
+  int reserve_nodes = 0, reserve_cuts = 0, node_cap = 0, staged_cut_type = 0; std::atomic<int> Btot_live{0}; bool append_closed = true; std::mutex append_mu; hipStream_t append_stream = nullptr;
   void* comm = nullptr; int comm_rank = 0, comm_world = 1; DevBuf bcomm, amobj; int amobj_B = 0;
   std::vector<double> rho_scale_per_node; DevBuf brho, brhon, blamD, bslotint, boY, boU, boal, bobx, boscal, boint;
   int Btot = 0;
@@ -304,6 +308,7 @@ void omc_instance_destroy(omc_instance* h) {
     for (int q = 0; q < 5; ++q) if (h->gev[g][q]) (void)hipEventDestroy(h->gev[g][q]);
   }
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+  if (h->append_stream) (void)hipStreamDestroy(h->append_stream);
   delete h;
 }
 
@@ -347,28 +352,16 @@ static hipEvent_t next_event(omc_instance* h) {
   } while (0)
 #define TIMED(cls, units_, call) TIMED_ON(h->stream, cls, units_, call)
 
-int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
-                    const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
-                    const double* U_upper) {
-  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
-  if (B <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
-  if (cut_type != OMC_CUT_LINEAR && cut_type != OMC_CUT_LINEAR2 && cut_type != OMC_CUT_LINEAR3)
-    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type: must be linear, linear2 or linear3 (OMC.jl:1456-1462)");
-  HIPCHK(hipSetDevice(h->device));
-  h->staged = false;
-  const bool shor = h->shor_req;      // set by omc_relax_stage_shor for this call only
-  h->shor_req = false; h->shor_on = false; h->shor_via_base = false;
-  if (params) h->params = *params; else omc_relax_params_default(&h->params);
-  if (shor) {      // the bound of a Shor node lags its primal value for the first ~1000 iterations: no early stop, a longer stall window, one bump
-    h->params.early_stop_factor = 0.0;
-    h->params.stall_checks = std::max(h->params.stall_checks, 40);
-    h->params.bump_max = std::min(h->params.bump_max, 1);
-    h->params.first_wins = 0; h->params.accel = 0;
-  }
-  const omc_relax_params& P = h->params;
-  if (P.breakpoints != OMC_SMALLEST_1_EIGVEC && P.breakpoints != OMC_SMALLEST_2_EIGVEC)
-    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts breakpoints (OMC.jl:2440-2446)");
-  const int n = h->n, m = h->m, k = h->k;
+// rows (OMC.jl:1558-1685) and row subspace of a set of nodes, on the host: shared by omc_relax_stage and omc_relax_append
+struct NodePack {
+  std::vector<std::vector<int>> rk, rc, rbi, rbj;
+  std::vector<std::vector<double>> rcoef, rrhs, Qn;
+  std::vector<int> rrv;
+  int Rmax = 0, rmax = 1, Lmax = 0;
+};
+static int pack_nodes(omc_instance* h, const omc_relax_params& P, int cut_type, int B, const int* L, const double* cut_x, const double* cut_Uhat,
+                      const int8_t* cut_dir, const double* U_lower, const double* U_upper, NodePack& pk) {
+  const int n = h->n, k = h->k;
   // ---- rows (host) -----------------------------------------------------------------------------------
   int Lmax = 0; long Ltot = 0;
   for (int b = 0; b < B; ++b) {
@@ -378,8 +371,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   }
   if (Ltot > 0 && (!cut_x || !cut_Uhat || !cut_dir)) return fail(OMC_ERR_ARGUMENT, "cut arrays are NULL but L > 0");
   // box rows: entries whose bound is not implied by ||U_j|| <= 1 (OMC.jl:1561, defaults 1442-1449)
-  std::vector<std::vector<int>> rk(B), rc(B), rbi(B), rbj(B);
-  std::vector<std::vector<double>> rcoef(B), rrhs(B);
+  auto& rk = pk.rk; auto& rc = pk.rc; auto& rbi = pk.rbi; auto& rbj = pk.rbj; auto& rcoef = pk.rcoef; auto& rrhs = pk.rrhs;
+  rk.assign(B, {}); rc.assign(B, {}); rbi.assign(B, {}); rbj.assign(B, {}); rcoef.assign(B, {}); rrhs.assign(B, {});
   int Rmax = 0;
   long cutbase = 0;
   for (int b = 0; b < B; ++b) {
@@ -421,8 +414,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     Rmax = std::max(Rmax, (int)rk[b].size());
   }
   // ---- subspace of the U functionals: modified Gram-Schmidt (twice) over the row vectors in row order ------
-  std::vector<std::vector<double>> Qn(B);
-  std::vector<int> rrv(B, 0);
+  auto& Qn = pk.Qn; auto& rrv = pk.rrv;
+  Qn.assign(B, {}); rrv.assign(B, 0);
   int rmax = 1;
   cutbase = 0;
   for (int b = 0; b < B; ++b) {
@@ -466,13 +459,53 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     rrv[b] = r; rmax = std::max(rmax, r);
     cutbase += Lb;
   }
+  pk.Rmax = Rmax; pk.rmax = rmax; pk.Lmax = Lmax;
+  return 0;
+}
+
+int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int cut_type, const int* L,
+                    const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir, const double* U_lower,
+                    const double* U_upper) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (B <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
+  if (cut_type != OMC_CUT_LINEAR && cut_type != OMC_CUT_LINEAR2 && cut_type != OMC_CUT_LINEAR3)
+    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts type: must be linear, linear2 or linear3 (OMC.jl:1456-1462)");
+  HIPCHK(hipSetDevice(h->device));
+  h->staged = false;
+  const bool shor = h->shor_req;      // set by omc_relax_stage_shor for this call only
+  h->shor_req = false; h->shor_on = false; h->shor_via_base = false;
+  if (params) h->params = *params; else omc_relax_params_default(&h->params);
+  if (shor) {      // the bound of a Shor node lags its primal value for the first ~1000 iterations: no early stop, a longer stall window, one bump
+    h->params.early_stop_factor = 0.0;
+    h->params.stall_checks = std::max(h->params.stall_checks, 40);
+    h->params.bump_max = std::min(h->params.bump_max, 1);
+    h->params.first_wins = 0; h->params.accel = 0;
+  }
+  const omc_relax_params& P = h->params;
+  if (P.breakpoints != OMC_SMALLEST_1_EIGVEC && P.breakpoints != OMC_SMALLEST_2_EIGVEC)
+    return fail(OMC_ERR_INVALID_ENUM, "Invalid input for disjunctive cuts breakpoints (OMC.jl:2440-2446)");
+  const int n = h->n, m = h->m, k = h->k;
+  // ---- rows and row subspaces (host) ---------------------------------------------------------------------
+  NodePack pk;
+  { int rcp = pack_nodes(h, P, cut_type, B, L, cut_x, cut_Uhat, cut_dir, U_lower, U_upper, pk); if (rcp) return rcp; }
+  auto& rk = pk.rk; auto& rc = pk.rc; auto& rbi = pk.rbi; auto& rbj = pk.rbj; auto& rcoef = pk.rcoef; auto& rrhs = pk.rrhs; auto& Qn = pk.Qn; auto& rrv = pk.rrv;
+  int Rmax = pk.Rmax, rmax = pk.rmax, Lmax = pk.Lmax;
+  long cutbase = 0;
+  // omc_relax_reserve: room for nodes appended later (default U bounds, at most reserve_cuts cuts each)
+  const int extra_nodes = shor ? 0 : h->reserve_nodes, extra_cuts = shor ? 0 : h->reserve_cuts;
+  h->reserve_nodes = 0; h->reserve_cuts = 0;
+  if (extra_nodes > 0) {
+    Lmax = std::max(Lmax, extra_cuts);
+    Rmax = std::max(Rmax, 1 + k * (k + 1) / 2 + extra_cuts * (2 * k + 1));
+    rmax = std::max(rmax, std::min(n, k + extra_cuts));
+  }
   // ---- workspace -------------------------------------------------------------------------------------
   OmcWS& w = h->ws;
   memset(&w, 0, sizeof(w));
   // continuous batching: S slots relax B nodes; a slot that finishes is harvested and re-used for the next pending node
   int S = (P.slots > 0) ? std::min(P.slots, B) : std::min(B, 256);
   if (h->tun.get("OMC_SLOTS")) S = std::max(1, std::min(B, atoi(h->tun.get("OMC_SLOTS"))));
-  h->Btot = B;
+  h->Btot = B; h->Btot_live.store(B); h->node_cap = B + extra_nodes; h->staged_cut_type = cut_type; { std::lock_guard<std::mutex> lk(h->append_mu); h->append_closed = false; }
   w.b0 = 0; w.nB = S;
   w.B = S; w.Btot = B; w.max_iters = P.max_iters; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
   w.jacobi_tau = h->tun.get("OMC_JACOBI_TAU") ? atof(h->tun.get("OMC_JACOBI_TAU")) : 0.0;
@@ -492,11 +525,11 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   w.accel = P.accel ? 1 : 0; w.aa_mem = std::max(2, std::min(P.aa_mem, AA_MAXMEM)); w.aa_every = std::max(1, P.aa_every);
   w.aa_start = std::max(2, P.aa_start); w.aa_reg = P.aa_reg; w.aa_safeguard = P.aa_safeguard;
   {
-    std::vector<double> hr(B, w.rho);
+    std::vector<double> hr((size_t)B + extra_nodes, w.rho);
     if (h->rho_scale_per_node.size() == (size_t)B)
       for (int b = 0; b < B; ++b) hr[b] = w.rho / P.rho_scale * h->rho_scale_per_node[b];
     h->rho_scale_per_node.clear();
-    int r0 = upload(h->brhon, hr.data(), sizeof(double) * B, h->stream); if (r0) return r0;
+    int r0 = upload(h->brhon, hr.data(), sizeof(double) * hr.size(), h->stream); if (r0) return r0;
     HIPCHK(hipStreamSynchronize(h->stream));          // hr dies with this block: the copy must have read it
     w.rho_node = h->brhon.as<double>();
     r0 = h->brho.ensure(sizeof(double) * (size_t)S); if (r0) return r0;
@@ -522,7 +555,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   w.row_ptr = h->drow_ptr.as<int>(); w.row_idx = h->drow_idx.as<int>();
 #define ENS(buf, bytes) do { int r_ = (buf).ensure(bytes); if (r_) return r_; } while (0)
   const size_t sB = (size_t)S;      // state arrays: one per slot
-  const size_t sN = (size_t)B;      // descriptor and output arrays: one per node
+  const size_t sN = (size_t)B + (size_t)extra_nodes;      // descriptor and output arrays: one per node (plus the room reserved for appended nodes)
   ENS(h->bY, sB * n * n * 8); ENS(h->bYp, sB * n * n * 8); ENS(h->bU, sB * n * k * 8);
   ENS(h->bD1, sB * n * n * 8); ENS(h->bD3, sB * n * n * 8); ENS(h->bW1, sB * n * n * 8); ENS(h->bE3, sB * n * n * 8);
   ENS(h->bdS, sB * rmax * rmax * 8);
@@ -623,9 +656,17 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   }
   // warm-start indices of this batch (consumed: they belong to this stage call only)
   w.load_from = nullptr; w.save_to = nullptr;
-  if (h->pool_cap > 0 && !shor && (h->warm_load.size() == (size_t)B || h->warm_save.size() == (size_t)B)) {
-    if (h->warm_load.size() == (size_t)B) { if ((rc_ = upload(h->bwarmL, h->warm_load.data(), sizeof(int) * B, h->stream))) return rc_; w.load_from = h->bwarmL.as<int>(); }
-    if (h->warm_save.size() == (size_t)B) { if ((rc_ = upload(h->bwarmS, h->warm_save.data(), sizeof(int) * B, h->stream))) return rc_; w.save_to = h->bwarmS.as<int>(); }
+  if (h->pool_cap > 0 && !shor && extra_nodes > 0) {      // appended nodes may name pool entries: both index arrays exist, -1 where nothing was given
+    if (h->warm_load.size() != (size_t)B) h->warm_load.assign(B, -1);
+    if (h->warm_save.size() != (size_t)B) h->warm_save.assign(B, -1);
+    h->warm_load.resize(sN, -1); h->warm_save.resize(sN, -1);
+  } else if (extra_nodes == 0) {
+    if (h->warm_load.size() != (size_t)B) h->warm_load.clear();
+    if (h->warm_save.size() != (size_t)B) h->warm_save.clear();
+  }
+  if (h->pool_cap > 0 && !shor && (h->warm_load.size() == sN || h->warm_save.size() == sN)) {
+    if (h->warm_load.size() == sN) { if ((rc_ = upload(h->bwarmL, h->warm_load.data(), sizeof(int) * sN, h->stream))) return rc_; w.load_from = h->bwarmL.as<int>(); }
+    if (h->warm_save.size() == sN) { if ((rc_ = upload(h->bwarmS, h->warm_save.data(), sizeof(int) * sN, h->stream))) return rc_; w.save_to = h->bwarmS.as<int>(); }
     HIPCHK(hipStreamSynchronize(h->stream));
     w.pY = h->pY.as<double>(); w.pD1 = h->pD1.as<double>(); w.pD3 = h->pD3.as<double>(); w.pU = h->pU.as<double>(); w.palpha = h->palpha.as<double>();
     w.psval = h->psval.as<double>(); w.pXs = h->pXs.as<double>(); w.ptheta = h->ptheta.as<double>(); w.pscal = h->pscal.as<double>();
@@ -636,12 +677,13 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
     std::vector<double> hQ(sN * n * rmax, 0.0);
     for (int b = 0; b < B; ++b) memcpy(&hQ[(size_t)b * n * rmax], Qn[b].data(), sizeof(double) * Qn[b].size());
     if ((rc_ = upload(h->bQb, hQ.data(), sizeof(double) * hQ.size(), h->stream))) return rc_;
-    if ((rc_ = upload(h->brr, rrv.data(), sizeof(int) * B, h->stream))) return rc_;
+    rrv.resize(sN, 0);
+    if ((rc_ = upload(h->brr, rrv.data(), sizeof(int) * sN, h->stream))) return rc_;
     HIPCHK(hipStreamSynchronize(h->stream));          // hQ dies with this block
     w.Qb = h->bQb.as<double>(); w.rr = h->brr.as<int>();
   }
   // rows upload (padded to Rmax)
-  std::vector<int> hR(B), hk(sN * Rmax, 0), hc(sN * Rmax, 0), hbi(sN * Rmax, 0), hbj(sN * Rmax, 0);
+  std::vector<int> hR(sN, 0), hk(sN * Rmax, 0), hc(sN * Rmax, 0), hbi(sN * Rmax, 0), hbj(sN * Rmax, 0);
   std::vector<double> hcoef(sN * Rmax * k, 0.0), hrhs(sN * Rmax, 0.0), hx(sN * w.Lmax * n, 0.0);
   cutbase = 0;
   for (int b = 0; b < B; ++b) {
@@ -657,7 +699,7 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
       memcpy(&hx[((size_t)b * w.Lmax + l) * n], cut_x + (size_t)(cutbase + l) * n, sizeof(double) * n);
     cutbase += Lb;
   }
-  if ((rc_ = upload(h->bR, hR.data(), sizeof(int) * B, h->stream))) return rc_;
+  if ((rc_ = upload(h->bR, hR.data(), sizeof(int) * sN, h->stream))) return rc_;
   if ((rc_ = upload(h->brkind, hk.data(), sizeof(int) * hk.size(), h->stream))) return rc_;
   if ((rc_ = upload(h->brcut, hc.data(), sizeof(int) * hc.size(), h->stream))) return rc_;
   if ((rc_ = upload(h->brbi, hbi.data(), sizeof(int) * hbi.size(), h->stream))) return rc_;
@@ -790,7 +832,8 @@ int omc_relax_solve(omc_instance* h) {
   h->ev_used = 0; h->ev_class.clear();
   auto t0 = std::chrono::steady_clock::now();
   hipStream_t s = h->stream;
-  const int S = w.B, Btot = w.Btot;
+  const int S = w.B; int Btot = h->Btot_live.load();      // nodes staged so far: omc_relax_append may add more while this loop runs (re-read at every check)
+  struct CloseGuard { omc_instance* h; ~CloseGuard() { std::lock_guard<std::mutex> lk(h->append_mu); h->append_closed = true; h->ws.Btot = h->Btot_live.load(); h->Btot = h->ws.Btot; } } close_guard{h};
   // slot bookkeeping on the host: node of each slot (-1 = idle), next pending node
   std::vector<int> node_of(S), flags(3 * (size_t)S), done(S, 0);
   for (int b = 0; b < S; ++b) node_of[b] = b;
@@ -918,7 +961,40 @@ int omc_relax_solve(omc_instance* h) {
     if (with_aa) MAYBE_TIMED(sm, OMC_KERNEL_ACCEL, gact[g], omc_launch_aa(&wg, sm));
     return 0;
   };
-  while (nactive > 0) {
+  // nodes appended while every slot was idle (or while the loop was about to end): hand them to idle slots
+  auto refill_idle = [&]() -> int {
+    std::vector<int> init2(S, 0), fin2(S, 0);
+    int ninit2 = 0;
+    for (int b = 0; b < S && next < Btot; ++b) if (node_of[b] < 0) { node_of[b] = next++; init2[b] = 1; parked[b] = 0; ++ninit2; }
+    if (!ninit2) return 0;
+    int rc = push_flags(init2, fin2); if (rc) return rc;
+    TIMED(OMC_KERNEL_SETUP, ninit2, omc_launch_setup(&w, s));
+    nactive = 0; gact[0] = gact[1] = 0;
+    for (int b = 0; b < S; ++b) if (node_of[b] >= 0) { ++nactive; if (!parked[b]) ++gact[(G == 2 && b >= gb0[1]) ? 1 : 0]; }
+    rc = push_list(); if (rc) return rc;
+    wait_main = true;
+    return 0;
+  };
+  for (;;) {
+    if (nactive == 0) {
+      {   // the end of the batch is decided under the lock omc_relax_append takes: a node is either seen here or refused there
+        std::lock_guard<std::mutex> lk(h->append_mu);
+        Btot = h->Btot_live.load();
+        if (timed_out && next < Btot) {      // appended after the time limit struck: reported as TIME_LIMIT without values, like the nodes that never got a slot
+          std::vector<int> st(Btot - next, OMC_ST_TIME), itz(Btot - next, 0);
+          std::vector<double> inf(Btot - next, 1e300), ninf(Btot - next, -1e300);
+          HIPCHK(hipMemcpyAsync(w.ostatus + next, st.data(), sizeof(int) * st.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(w.oiters + next, itz.data(), sizeof(int) * itz.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(w.oobj + next, inf.data(), 8 * inf.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(w.olb + next, ninf.data(), 8 * ninf.size(), hipMemcpyHostToDevice, s));
+          HIPCHK(hipStreamSynchronize(s));
+          next = Btot;
+        }
+        if (next >= Btot) { h->append_closed = true; break; }
+      }
+      int rc = refill_idle(); if (rc) return rc;
+      continue;
+    }
     ++it;
     const bool is_check = (it % check == 0);
     if (multi && wait_main) HIPCHK(hipEventRecord(h->ev_main, s));
@@ -982,6 +1058,7 @@ int omc_relax_solve(omc_instance* h) {
     });
     HIPCHK(hipMemcpyAsync(done.data(), w.done, sizeof(int) * S, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    Btot = h->Btot_live.load();
     if (P.first_wins) {   // the first certified node ends the batch (penalty autotune): everything still running is harvested as it stands
       std::vector<int> stv(S);
       HIPCHK(hipMemcpyAsync(stv.data(), w.status, sizeof(int) * S, hipMemcpyDeviceToHost, s));
@@ -1045,6 +1122,7 @@ int omc_relax_solve(omc_instance* h) {
     nactive = 0; gact[0] = gact[1] = 0;
     for (int b = 0; b < S; ++b) if (node_of[b] >= 0) { ++nactive; if (!parked[b]) ++gact[(G == 2 && b >= gb0[1]) ? 1 : 0]; }
     if (nfin || nnew) { int rc = push_list(); if (rc) return rc; }
+    if (next < Btot && !timed_out && nactive < S) { int rc = refill_idle(); if (rc) return rc; }      // appended nodes for slots that had gone idle
     if (timed_out && next < Btot) {
       // nodes that never got a slot: report TIME_LIMIT without values
       std::vector<int> st(Btot - next, OMC_ST_TIME), itz(Btot - next, 0);
@@ -1086,6 +1164,77 @@ int omc_relax_solve(omc_instance* h) {
   return 0;
 }
 
+// ---- appending nodes to a staged / running batch ------------------------------------------------------------------------------------------
+// The reference's loop pops one node at a time from a queue that children keep filling (OMC.jl:700-719, 2520-2542); a staged batch is closed.
+// omc_relax_reserve(h, extra_nodes, max_cuts) makes the NEXT omc_relax_stage size its per-node arrays for extra_nodes more nodes with at most
+// max_cuts cuts each (default U bounds); omc_relax_append then adds nodes -- before omc_relax_solve / omc_relax_submit or while the submitted
+// solve is running (the loop hands them to slots at its next check) -- until the solve has ended, after which it is refused.
+int omc_relax_reserve(omc_instance* h, int extra_nodes, int max_cuts) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  if (extra_nodes < 0 || max_cuts < 0) return fail(OMC_ERR_ARGUMENT, "omc_relax_reserve: negative argument");
+  h->reserve_nodes = extra_nodes; h->reserve_cuts = max_cuts;
+  return 0;
+}
+
+int omc_relax_append(omc_instance* h, int B2, const int* L, const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir,
+                     const int* load_from, const int* save_to) {
+  if (!h || !h->staged) return fail(OMC_ERR_ARGUMENT, "omc_relax_append: nothing staged");
+  if (B2 <= 0) return fail(OMC_ERR_ARGUMENT, "B must be positive");
+  if (h->shor_on) return fail(OMC_ERR_UNSUPPORTED, "omc_relax_append: not available in Shor mode");
+  HIPCHK(hipSetDevice(h->device));
+  std::lock_guard<std::mutex> lk(h->append_mu);
+  if (h->append_closed) return fail(OMC_ERR_ARGUMENT, "omc_relax_append: the solve of this batch has ended (stage a new batch)");
+  const OmcWS& w = h->ws;
+  const int first = h->Btot_live.load();
+  if (first + B2 > h->node_cap) return fail(OMC_ERR_ARGUMENT, "omc_relax_append: beyond the capacity given to omc_relax_reserve");
+  NodePack pk;
+  { int rcp = pack_nodes(h, h->params, h->staged_cut_type, B2, L, cut_x, cut_Uhat, cut_dir, nullptr, nullptr, pk); if (rcp) return rcp; }
+  if (pk.Rmax > w.Rmax || pk.rmax > w.rmax || pk.Lmax > w.Lmax) return fail(OMC_ERR_ARGUMENT, "omc_relax_append: a node has more cuts than omc_relax_reserve allowed for");
+  const size_t n = h->n, k = h->k, Rm = w.Rmax, rm = w.rmax, Lm = w.Lmax;
+  std::vector<int> hR(B2), hk((size_t)B2 * Rm, 0), hc((size_t)B2 * Rm, 0), hbi((size_t)B2 * Rm, 0), hbj((size_t)B2 * Rm, 0);
+  std::vector<double> hcoef((size_t)B2 * Rm * k, 0.0), hrhs((size_t)B2 * Rm, 0.0), hx((size_t)B2 * Lm * n, 0.0), hQ((size_t)B2 * n * rm, 0.0), hrho(B2, w.rho);
+  long cutbase = 0;
+  for (int b = 0; b < B2; ++b) {
+    hR[b] = (int)pk.rk[b].size();
+    for (int r = 0; r < hR[b]; ++r) {
+      hk[(size_t)b * Rm + r] = pk.rk[b][r]; hc[(size_t)b * Rm + r] = pk.rc[b][r];
+      hbi[(size_t)b * Rm + r] = pk.rbi[b][r]; hbj[(size_t)b * Rm + r] = pk.rbj[b][r];
+      hrhs[(size_t)b * Rm + r] = pk.rrhs[b][r];
+      for (size_t j = 0; j < k; ++j) hcoef[((size_t)b * Rm + r) * k + j] = pk.rcoef[b][(size_t)r * k + j];
+    }
+    const int Lb = L ? L[b] : 0;
+    for (int l = 0; l < Lb; ++l) memcpy(&hx[((size_t)b * Lm + l) * n], cut_x + (size_t)(cutbase + l) * n, sizeof(double) * n);
+    cutbase += Lb;
+    memcpy(&hQ[(size_t)b * n * rm], pk.Qn[b].data(), sizeof(double) * pk.Qn[b].size());
+  }
+  if ((load_from || save_to) && !(w.load_from && w.save_to)) return fail(OMC_ERR_ARGUMENT, "omc_relax_append: warm-start indices need a state pool created before the batch was staged");
+  for (int b = 0; b < B2; ++b) {
+    if (load_from && load_from[b] >= h->pool_cap) return fail(OMC_ERR_ARGUMENT, "load_from index beyond the pool");
+    if (save_to && save_to[b] >= h->pool_cap) return fail(OMC_ERR_ARGUMENT, "save_to index beyond the pool");
+  }
+  if (!h->append_stream) HIPCHK(hipStreamCreateWithFlags(&h->append_stream, hipStreamNonBlocking));
+  hipStream_t as = h->append_stream;
+  const size_t f = (size_t)first;
+  // the running kernels read the descriptors of nodes below Btot_live only: these rows are not visible to them until the counter moves
+  HIPCHK(hipMemcpyAsync(w.R + f, hR.data(), sizeof(int) * B2, hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.rkind + f * Rm, hk.data(), sizeof(int) * hk.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.rcut + f * Rm, hc.data(), sizeof(int) * hc.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.rbi + f * Rm, hbi.data(), sizeof(int) * hbi.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.rbj + f * Rm, hbj.data(), sizeof(int) * hbj.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.rcoef + f * Rm * k, hcoef.data(), 8 * hcoef.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.rrhs + f * Rm, hrhs.data(), 8 * hrhs.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.cutx + f * Lm * n, hx.data(), 8 * hx.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.Qb + f * n * rm, hQ.data(), 8 * hQ.size(), hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(w.rr + f, pk.rrv.data(), sizeof(int) * B2, hipMemcpyHostToDevice, as));
+  HIPCHK(hipMemcpyAsync(const_cast<double*>(w.rho_node) + f, hrho.data(), 8 * (size_t)B2, hipMemcpyHostToDevice, as));
+  if (load_from) HIPCHK(hipMemcpyAsync(const_cast<int*>(w.load_from) + f, load_from, sizeof(int) * B2, hipMemcpyHostToDevice, as));
+  if (save_to) HIPCHK(hipMemcpyAsync(const_cast<int*>(w.save_to) + f, save_to, sizeof(int) * B2, hipMemcpyHostToDevice, as));
+  HIPCHK(hipStreamSynchronize(as));
+  h->Btot_live.store(first + B2); h->Btot = first + B2;
+  if (!h->worker_running.load()) h->ws.Btot = first + B2;      // no solve in flight: the staged batch simply grew
+  return 0;
+}
+
 // ---- asynchronous boundary: the solve runs on a worker thread of the library, the caller (the Julia task that owns the queue) keeps
 // working -- popping, pruning, building the next batch -- and polls.  One solve in flight per handle; no other call on the handle
 // except omc_relax_poll until omc_relax_wait has returned.
@@ -1106,7 +1255,7 @@ int omc_relax_poll(omc_instance* h, int* running, int* nodes_done, int* nodes_to
   if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
   if (running) *running = h->worker_running.load();
   if (nodes_done) *nodes_done = h->nodes_done.load();
-  if (nodes_total) *nodes_total = h->Btot;
+  if (nodes_total) *nodes_total = h->Btot_live.load();
   return 0;
 }
 

@@ -1188,3 +1188,65 @@ def test_left_singular_vectors_on_the_device(have_gpu, omc, orc):
         Xk, Uk = omc.pkg.bnb.rank_k_projection(root["X"], k, eng)
         assert np.linalg.matrix_rank(Xk, tol=1e-9) <= k and np.allclose(Uk, got[2])
         eng.close()
+
+
+def test_append_nodes_to_a_staged_and_to_a_running_batch(have_gpu, omc):
+    """omc_relax_reserve / omc_relax_append: nodes added to a staged batch before the solve, and nodes added while the submitted solve is
+    running (the loop hands them to free slots at its next check), come back with the results the same nodes have when they are all staged
+    together -- bit for bit, a node's relaxation does not depend on the slot or the moment it starts.  With warm starts from the pool as well;
+    refused beyond the reserved capacity, with more cuts than reserved, and after the solve has ended."""
+    import time
+    A, mask, gamma, c = omc.pkg.data.config_instance(2, seed=0)
+    eng = omc.Engine(A, mask, gamma, 1)
+    P = omc.default_params(rho_scale=4.0, slots=32)
+    nodes, _ = omc.pkg.bnb.expand_frontier(eng, 6, "linear", params=omc.default_params(rho_scale=4.0))
+    assert len(nodes) == 64
+    ref = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_X=False, want_Y=False)
+    key = lambda o: (o["objective"], o["dual_bound"], o["iters"], o["status_code"])
+    # (a) appended before the solve starts
+    eng.reserve(48, 6)
+    eng.stage(nodes[:16], "linear", P)
+    eng.append(nodes[16:40], "linear")
+    eng.append(nodes[40:], "linear")
+    eng.solve()
+    got = eng.fetch(want_Y=False, want_X=False)
+    assert [key(o) for o in got] == [key(o) for o in ref]
+    # (b) appended while the solve is running (16 nodes through 32 slots: slots are idle until the first append arrives)
+    eng.reserve(48, 6)
+    eng.stage(nodes[:16], "linear", P)
+    eng.submit()
+    eng.append(nodes[16:40], "linear")
+    time.sleep(0.05)
+    eng.append(nodes[40:], "linear")
+    assert eng.poll()["nodes_total"] == 64
+    eng.wait()
+    got = eng.fetch(want_Y=False, want_X=False)
+    assert [key(o) for o in got] == [key(o) for o in ref]
+    with pytest.raises(omc.OmcError):
+        eng.append(nodes[:1], "linear")                                   # the solve has ended
+    # (c) limits
+    eng.reserve(4, 2)
+    eng.stage([[]] * 4, "linear", P)
+    with pytest.raises(omc.OmcError):
+        eng.append(nodes[:1], "linear")                                   # six cuts, two reserved
+    with pytest.raises(omc.OmcError):
+        eng.append([[]] * 5, "linear")                                    # beyond the capacity
+    eng.append([nodes[0][:2]] * 4, "linear")
+    eng.solve()
+    out = eng.fetch(want_Y=False, want_X=False)
+    assert len(out) == 8 and all(key(o) == key(out[0]) for o in out[1:4]) and all(key(o) == key(out[4]) for o in out[5:])
+    # (d) warm starts from the pool for appended nodes
+    parents = [list(cuts[:-1]) for cuts in nodes[::2]]
+    eng.state_pool_create(len(parents))
+    eng.matrix_completion_SDP_relaxation(parents, "linear", params=P, want_X=False, want_Y=False, save_to=list(range(len(parents))))
+    lf = [i // 2 for i in range(len(nodes))]
+    refw = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_X=False, want_Y=False, load_from=lf)
+    eng.reserve(48, 6)
+    eng.stage(nodes[:16], "linear", P, load_from=lf[:16])
+    eng.submit()
+    eng.append(nodes[16:], "linear", load_from=lf[16:])
+    eng.wait()
+    gotw = eng.fetch(want_Y=False, want_X=False)
+    assert [key(o) for o in gotw] == [key(o) for o in refw]
+    assert sum(o["iters"] for o in gotw) < sum(o["iters"] for o in ref)   # and they did start warm
+    eng.close()
