@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--warm", type=int, default=int(os.environ.get("OMC_BENCH_WARM", 1)), help="1: every node starts from its parent's final state (omc_relax_set_warm), as in a B&B run where "
                     "a child is relaxed after its parent -- the ancestors are relaxed level by level before the timed region, each from its own parent's state; "
                     "2: only the frontier's parents are relaxed beforehand, cold; 0: cold starts (the reference rebuilds every model, OMC.jl:1482)")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("OMC_BENCH_PIPELINE", 1)), help="1: the K timed steps are K batches handed to the engine as one stream (continuous batching: "
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("OMC_BENCH_PIPELINE", 2)), help="1: the K timed steps are K batches handed to the engine as one stream (continuous batching: "
                     "the slots a batch frees while its last nodes converge are refilled from the next batch, as a B&B queue that always holds open nodes would); "
+                    "2: the same, but batches 2..K are appended to the RUNNING solve of batch 1 (omc_relax_reserve / omc_relax_append), descriptors uploaded inside the timed region; "
                     "0: each step is staged, solved and drained on its own (rounds 1-2)")
     ap.add_argument("--early-stop", type=float, default=None, help="early_stop_factor of the relaxation parameters (library default 1.5; 0 = rule off)")
     ap.add_argument("--extras", type=int, default=1, help="0: skip latency_b1 / branching / time_to_gap / cpu_baseline (rank 0, N=1 only)")
@@ -291,13 +292,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     pipelined = bool(args.pipeline) and args.steps > 1
-    if pipelined:      # the K batches as one stream: node b of batch s is node s * B + b (descriptors and parent states resident before the clock starts)
+    appended = pipelined and args.pipeline == 2
+    if appended:       # --pipeline 2: the first batch is staged with room for the others, which are APPENDED to the running solve (omc_relax_append)
+        eng.reserve(B * (args.steps - 1), max(len(c) for c in nodes))
+        eng.stage(nodes, cfg["cut_type"], P, load_from=load_from)
+        torch.cuda.synchronize()
+    elif pipelined:    # the K batches as one stream: node b of batch s is node s * B + b (descriptors and parent states resident before the clock starts)
         eng.stage(nodes * args.steps, cfg["cut_type"], P, load_from=None if load_from is None else load_from * args.steps)
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s_ in range(1 if pipelined else args.steps):
         if pipelined:
-            eng.solve()
+            if appended:
+                eng.submit()
+                for q in range(1, args.steps):                    # host -> device of the descriptors is inside the timed region here
+                    eng.append(nodes, cfg["cut_type"], load_from=load_from)
+                eng.wait()
+            else:
+                eng.solve()
             out_all = eng.fetch(want_Y=False, want_X=False)
             for q in range(args.steps):                      # one bound exchange per batch, as in the step-by-step form
                 exchange(out_all[q * B:(q + 1) * B])
@@ -480,8 +492,9 @@ def main():
                                    f"{B} depth-{args.depth} frontier nodes per GPU per step streamed through {min(args.slots, B)} slots (continuous batching, "
                                    + ("every node warm-started from its parent's final state" if args.warm else "cold starts")
                                    + (", each rank its own subtrees" if world > 1 else "")
-                                   + (f"; the {args.steps} steps are {args.steps} batches handed over as one stream: slots freed while a batch's last nodes converge are refilled from the next batch" if pipelined else "") + ")",
-                       "nodes_per_gpu": B, "slots": min(args.slots, B), "pipelined_batches": pipelined, "warm_start": bool(args.warm), "parent_states_in_pool": n_parents, "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
+                                   + (f"; the {args.steps} steps are {args.steps} batches handed over as one stream: slots freed while a batch's last nodes converge are refilled from the next batch"
+                                      + (" (batches 2.. are appended to the running solve of batch 1: omc_relax_append, descriptor upload inside the timed region)" if appended else "") if pipelined else "") + ")",
+                       "nodes_per_gpu": B, "slots": min(args.slots, B), "pipelined_batches": pipelined, "appended_to_running_solve": appended, "warm_start": bool(args.warm), "parent_states_in_pool": n_parents, "rho_scale": rho_scale, "eps_gap": 1e-6, "iters_median": int(np.median(iters)), "iters_max": int(iters.max()),
                        "status_counts": {"optimal": int(status[0]), "slow_progress": int(status[1]), "time_limit": int(status[2]), "infeasible": int(status[3])},
                        "certified_fraction": certified / B, "certified_nodes_per_s": value, "nodes_per_s_all": value_all,
                        "bounds_exchange": (comm_kind if use_comm else None),
