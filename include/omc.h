@@ -163,6 +163,14 @@ int omc_relax_submit(omc_instance* h);
  * submitted solve is running -- the loop hands them to free slots at its next check -- and is refused once that solve has ended (the end is
  * decided under the same lock, so a node is either relaxed or refused, never lost).  Results: omc_relax_fetch returns every node, appended
  * ones behind the staged ones in the order they were appended.  Not available in Shor mode. */
+/* omc_relax_fetch_done: results of the nodes finished since the last call, in the order they finished -- callable while the submitted solve is
+ * running (the other half of a queue-driven host loop: OMC.jl:700-719 pops, relaxes and pushes the children of one node at a time).
+ * node_ids[i] indexes the staged + appended nodes; per node: U (n*k), lambda_min (2), breakpoint_x (n) as in omc_relax_fetch (NULL: skipped). */
+int omc_relax_fetch_done(omc_instance* h, int max_nodes, int* node_ids, double* objective, double* dual_bound, int* status, int* iters,
+                         double* U, double* lambda_min, double* breakpoint_x, int* n_out);
+/* omc_relax_hold(h, 1) after staging: the submitted solve waits for omc_relax_append when it runs dry instead of ending (until omc_relax_hold(h, 0)
+ * or the time limit of the parameters). */
+int omc_relax_hold(omc_instance* h, int on);
 int omc_relax_reserve(omc_instance* h, int extra_nodes, int max_cuts);
 int omc_relax_append(omc_instance* h, int B, const int* L, const double* cut_x, const double* cut_Uhat, const int8_t* cut_dir,
                      const int* load_from, const int* save_to);

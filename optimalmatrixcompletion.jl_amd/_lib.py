@@ -15,7 +15,7 @@ EXPORTS = [
     "omc_relax_params_default", "omc_last_error", "omc_version", "omc_device_count", "omc_instance_create",
     "omc_instance_create_bits", "omc_instance_destroy", "omc_relax_batch", "omc_relax_stage", "omc_relax_solve",
     "omc_relax_fetch", "omc_relax_submit", "omc_relax_poll", "omc_relax_wait", "omc_altmin_batch", "omc_evaluate_objective", "omc_separation_batch", "omc_round_Y_batch",
-    "omc_last_kernel_stats", "omc_last_solver_info", "omc_last_subspace_stats", "omc_set_node_rho_scales", "omc_left_singular_batch", "omc_relax_reserve", "omc_relax_append", "omc_debug_stamps", "omc_tuning_set", "omc_tuning_reload_env", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
+    "omc_last_kernel_stats", "omc_last_solver_info", "omc_last_subspace_stats", "omc_set_node_rho_scales", "omc_left_singular_batch", "omc_relax_reserve", "omc_relax_append", "omc_relax_fetch_done", "omc_relax_hold", "omc_debug_stamps", "omc_tuning_set", "omc_tuning_reload_env", "omc_debug_residuals", "omc_debug_diag", "omc_debug_aa",
     "omc_shor_count", "omc_shor_indexes", "omc_violated_shor_minors", "omc_shor_last_stats",
     "omc_relax_stage_shor", "omc_relax_fetch_shor", "omc_relax_batch_shor", "omc_set_shor_penalties", "omc_set_shor_keep_V", "omc_relax_fetch_shor_V", "omc_last_shor_subspace_stats", "omc_state_pool_create", "omc_relax_set_warm",
     "omc_altmin_master_objectives", "omc_comm_unique_id", "omc_comm_init", "omc_allreduce_bounds", "omc_bcast_incumbent", "omc_allgather_records", "omc_comm_destroy",
@@ -85,6 +85,8 @@ def load():
     lib.omc_debug_stamps.argtypes = [vp, vp]
     lib.omc_left_singular_batch.argtypes = [vp, C.c_int, vp, vp]
     lib.omc_relax_reserve.argtypes = [vp, C.c_int, C.c_int]
+    lib.omc_relax_hold.argtypes = [vp, C.c_int]
+    lib.omc_relax_fetch_done.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.omc_relax_append.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.omc_tuning_set.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.omc_tuning_reload_env.argtypes = [vp]

@@ -241,6 +241,22 @@ class Engine:
         _lib.check(self._lib.omc_relax_append(self._h, len(nodes), _lib.ptr(L), _lib.ptr(cx), _lib.ptr(cU), _lib.ptr(cd), _lib.ptr(lf), _lib.ptr(sv)))
         self._B += len(nodes)
 
+    def hold(self, on=True):
+        """Keep the submitted solve open when it runs dry (omc_relax_hold): it waits for append() until hold(False)."""
+        _lib.check(self._lib.omc_relax_hold(self._h, 1 if on else 0))
+
+    def fetch_done(self, max_nodes=4096):
+        """Results of the nodes finished since the last call (omc_relax_fetch_done), also while the submitted solve is running: a list of dicts
+        with the keys of fetch() that a driver needs to branch (node = index among the staged + appended nodes)."""
+        n, k = self.n, self.k
+        ids = np.zeros(max_nodes, np.int32); obj = np.zeros(max_nodes); lb = np.zeros(max_nodes); st = np.zeros(max_nodes, np.int32); it = np.zeros(max_nodes, np.int32)
+        U = np.zeros((max_nodes, n * k)); ev = np.zeros((max_nodes, 2)); bx = np.zeros((max_nodes, n)); cnt = np.zeros(1, np.int32)
+        _lib.check(self._lib.omc_relax_fetch_done(self._h, int(max_nodes), _lib.ptr(ids), _lib.ptr(obj), _lib.ptr(lb), _lib.ptr(st), _lib.ptr(it),
+                                                  _lib.ptr(U), _lib.ptr(ev), _lib.ptr(bx), _lib.ptr(cnt)))
+        return [dict(node=int(ids[i]), objective=float(obj[i]), dual_bound=float(lb[i]), status_code=int(st[i]), termination_status=STATUS_NAMES[int(st[i])],
+                     feasible=int(st[i]) != 3, iters=int(it[i]), U=U[i].reshape((n, k), order="F").copy(), lambda_min=ev[i].copy(), breakpoint_vec=bx[i].copy())
+                for i in range(int(cnt[0]))]
+
     def solve(self):
         _lib.check(self._lib.omc_relax_solve(self._h))
 

@@ -143,6 +143,8 @@ struct omc_instance {
   // appending nodes to a staged / running batch (omc_relax_reserve, omc_relax_append): descriptor and output arrays are sized for node_cap nodes,
   // the strides (rows, row-subspace columns, cuts per node) for reserve_cuts cuts; Btot_live is what the solve loop reads at its refill points
   int reserve_nodes = 0, reserve_cuts = 0, node_cap = 0, staged_cut_type = 0; std::atomic<int> Btot_live{0}; bool append_closed = true; std::mutex append_mu; hipStream_t append_stream = nullptr;
+  std::atomic<int> hold{0};      // omc_relax_hold: a solve that has run dry waits for omc_relax_append instead of ending
+  std::vector<int> done_q; size_t done_read = 0; std::mutex done_mu; hipStream_t fetch_stream = nullptr;      // nodes harvested so far, in harvest order (omc_relax_fetch_done)
   void* comm = nullptr; int comm_rank = 0, comm_world = 1; DevBuf bcomm, amobj; int amobj_B = 0;
   std::vector<double> rho_scale_per_node; DevBuf brho, brhon, blamD, bslotint, boY, boU, boal, bobx, boscal, boint;
   int Btot = 0;
@@ -309,6 +311,7 @@ void omc_instance_destroy(omc_instance* h) {
   }
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   if (h->append_stream) (void)hipStreamDestroy(h->append_stream);
+  if (h->fetch_stream) (void)hipStreamDestroy(h->fetch_stream);
   delete h;
 }
 
@@ -506,6 +509,8 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   int S = (P.slots > 0) ? std::min(P.slots, B) : std::min(B, 256);
   if (h->tun.get("OMC_SLOTS")) S = std::max(1, std::min(B, atoi(h->tun.get("OMC_SLOTS"))));
   h->Btot = B; h->Btot_live.store(B); h->node_cap = B + extra_nodes; h->staged_cut_type = cut_type; { std::lock_guard<std::mutex> lk(h->append_mu); h->append_closed = false; }
+  { std::lock_guard<std::mutex> lk(h->done_mu); h->done_q.clear(); h->done_read = 0; }
+  h->hold.store(0);
   w.b0 = 0; w.nB = S;
   w.B = S; w.Btot = B; w.max_iters = P.max_iters; w.n = n; w.m = m; w.k = k; w.nnz = h->nnz; w.Rmax = Rmax; w.Lmax = std::max(Lmax, 1); w.rmax = rmax;
   w.jacobi_tau = h->tun.get("OMC_JACOBI_TAU") ? atof(h->tun.get("OMC_JACOBI_TAU")) : 0.0;
@@ -990,8 +995,12 @@ int omc_relax_solve(omc_instance* h) {
           HIPCHK(hipStreamSynchronize(s));
           next = Btot;
         }
-        if (next >= Btot) { h->append_closed = true; break; }
+        if (next >= Btot) {
+          const double el_idle = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          if (!h->hold.load() || el_idle > P.time_limit) { h->append_closed = true; break; }
+        }
       }
+      if (next >= Btot) { std::this_thread::sleep_for(std::chrono::microseconds(100)); continue; }      // held open (omc_relax_hold): wait for the host's next push
       int rc = refill_idle(); if (rc) return rc;
       continue;
     }
@@ -1110,13 +1119,16 @@ int omc_relax_solve(omc_instance* h) {
       });
       harvested += nfin; h->nodes_done.store(harvested);
       int ninit = 0;
+      std::vector<int> harvested_ids;
       for (int b = 0; b < S; ++b) {
         if (!fin[b]) continue;
         fin[b] = 0;
+        harvested_ids.push_back(node_of[b]);
         if (next < Btot && !timed_out) { node_of[b] = next++; init[b] = 1; ++ninit; }
         else node_of[b] = -1;
       }
-      rc = push_flags(init, fin); if (rc) return rc;
+      rc = push_flags(init, fin); if (rc) return rc;      // synchronises the stream: the harvest kernels have written the per-node outputs
+      { std::lock_guard<std::mutex> lk(h->done_mu); h->done_q.insert(h->done_q.end(), harvested_ids.begin(), harvested_ids.end()); }
       if (ninit) { if (shor) omc_shor_launch_setup(&sw, s); TIMED(OMC_KERNEL_SETUP, ninit, omc_launch_setup(&w, s)); }
     }
     nactive = 0; gact[0] = gact[1] = 0;
@@ -1232,6 +1244,50 @@ int omc_relax_append(omc_instance* h, int B2, const int* L, const double* cut_x,
   HIPCHK(hipStreamSynchronize(as));
   h->Btot_live.store(first + B2); h->Btot = first + B2;
   if (!h->worker_running.load()) h->ws.Btot = first + B2;      // no solve in flight: the staged batch simply grew
+  return 0;
+}
+
+// omc_relax_hold(h, 1) after staging: the submitted solve does not end when every staged node has finished but waits for omc_relax_append
+// (a queue-driven host creates the next nodes from the results of the last ones); omc_relax_hold(h, 0) lets it end once it runs dry.
+int omc_relax_hold(omc_instance* h, int on) {
+  if (!h) return fail(OMC_ERR_ARGUMENT, "handle is NULL");
+  h->hold.store(on ? 1 : 0);
+  return 0;
+}
+
+// Results of the nodes harvested since the last call, in harvest order -- also while the submitted solve is still running: with omc_relax_append
+// this is the other half of a queue-driven host loop (OMC.jl:700-719: pop, relax, push the children).  node_ids[i] indexes the staged + appended
+// nodes; U (n*k), lambda_min (2) and breakpoint_x (n) per node as in omc_relax_fetch (NULL: not copied).  *n_out = nodes returned (<= max_nodes).
+int omc_relax_fetch_done(omc_instance* h, int max_nodes, int* node_ids, double* objective, double* dual_bound, int* status, int* iters,
+                         double* U, double* lambda_min, double* breakpoint_x, int* n_out) {
+  if (!h || !h->staged || !node_ids || !n_out) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch_done: nothing staged or NULL argument");
+  if (max_nodes < 0) return fail(OMC_ERR_ARGUMENT, "max_nodes is negative");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<int> ids;
+  {
+    std::lock_guard<std::mutex> lk(h->done_mu);
+    const size_t avail = h->done_q.size() - h->done_read, take = std::min(avail, (size_t)max_nodes);
+    ids.assign(h->done_q.begin() + h->done_read, h->done_q.begin() + h->done_read + take);
+    h->done_read += take;
+  }
+  *n_out = (int)ids.size();
+  if (ids.empty()) return 0;
+  if (!h->fetch_stream) HIPCHK(hipStreamCreateWithFlags(&h->fetch_stream, hipStreamNonBlocking));
+  hipStream_t fs = h->fetch_stream;
+  const OmcWS& w = h->ws;
+  const size_t n = h->n, k = h->k;
+  for (size_t i = 0; i < ids.size(); ++i) {
+    const size_t nb = (size_t)ids[i];
+    node_ids[i] = ids[i];
+    if (objective) HIPCHK(hipMemcpyAsync(objective + i, w.oobj + nb, 8, hipMemcpyDeviceToHost, fs));
+    if (dual_bound) HIPCHK(hipMemcpyAsync(dual_bound + i, w.olb + nb, 8, hipMemcpyDeviceToHost, fs));
+    if (status) HIPCHK(hipMemcpyAsync(status + i, w.ostatus + nb, 4, hipMemcpyDeviceToHost, fs));
+    if (iters) HIPCHK(hipMemcpyAsync(iters + i, w.oiters + nb, 4, hipMemcpyDeviceToHost, fs));
+    if (U) HIPCHK(hipMemcpyAsync(U + i * n * k, w.oU + nb * n * k, 8 * n * k, hipMemcpyDeviceToHost, fs));
+    if (lambda_min) HIPCHK(hipMemcpyAsync(lambda_min + 2 * i, w.olmin + 2 * nb, 16, hipMemcpyDeviceToHost, fs));
+    if (breakpoint_x) HIPCHK(hipMemcpyAsync(breakpoint_x + i * n, w.obx + nb * n, 8 * n, hipMemcpyDeviceToHost, fs));
+  }
+  HIPCHK(hipStreamSynchronize(fs));
   return 0;
 }
 

@@ -1250,3 +1250,41 @@ def test_append_nodes_to_a_staged_and_to_a_running_batch(have_gpu, omc):
     assert [key(o) for o in gotw] == [key(o) for o in refw]
     assert sum(o["iters"] for o in gotw) < sum(o["iters"] for o in ref)   # and they did start warm
     eng.close()
+
+
+def test_queue_driven_loop_append_and_fetch_done(have_gpu, omc):
+    """omc_relax_fetch_done + omc_relax_append: a host loop in the shape of the reference's (OMC.jl:700-719) -- take the results of the nodes that
+    have finished so far, push new nodes for them -- against one staged batch: every node comes back exactly once through fetch_done, in
+    finishing order, with the values the batch call returns, while the solve keeps running until the host stops feeding it."""
+    import time
+    A, mask, gamma, c = omc.pkg.data.config_instance(2, seed=0)
+    eng = omc.Engine(A, mask, gamma, 1)
+    P = omc.default_params(rho_scale=4.0, slots=16)
+    nodes, _ = omc.pkg.bnb.expand_frontier(eng, 6, "linear", params=omc.default_params(rho_scale=4.0))
+    ref = eng.matrix_completion_SDP_relaxation(nodes, "linear", params=P, want_X=False, want_Y=False)
+    eng.reserve(len(nodes) - 8, 6)
+    eng.stage(nodes[:8], "linear", P)
+    eng.hold(True)                                                        # the solve waits for pushes when it runs dry
+    eng.submit()
+    sent, seen, deadline = 8, {}, time.time() + 120
+    while len(seen) < len(nodes) and time.time() < deadline:
+        got = eng.fetch_done()
+        for o in got:
+            assert o["node"] not in seen
+            seen[o["node"]] = o
+        if got and sent < len(nodes):                                     # two new nodes per finished one, as a split would push
+            more = min(2 * len(got), len(nodes) - sent)
+            eng.append(nodes[sent:sent + more], "linear")
+            sent += more
+        if not got:
+            time.sleep(0.002)
+    assert eng.poll()["running"]                                          # every node is back and the solve is still open
+    eng.hold(False)
+    eng.wait()
+    assert sorted(seen) == list(range(len(nodes)))
+    for i, o in seen.items():
+        r = ref[i]
+        assert (o["objective"], o["dual_bound"], o["iters"], o["status_code"]) == (r["objective"], r["dual_bound"], r["iters"], r["status_code"])
+        assert np.array_equal(o["U"], r["U"]) and np.array_equal(o["breakpoint_vec"], r["breakpoint_vec"])
+    assert eng.fetch_done() == []
+    eng.close()
