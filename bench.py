@@ -481,6 +481,16 @@ def main():
                                             iters_median=int(np.median([o_["iters"] for o_ in oc])), seconds=tc)
             except Exception as ex:
                 extras["cold_start"] = dict(error=repr(ex))
+            # ---- and the warm frontier as ONE batch drained to its last node (no next batch behind it): the per-step form of rounds 1-2 ------------
+            try:
+                eng.stage(nodes, cfg["cut_type"], P, load_from=load_from)
+                t1 = time.perf_counter(); eng.solve(); td = time.perf_counter() - t1
+                od = eng.fetch(want_Y=False, want_X=False)
+                std = np.bincount([o_["status_code"] for o_ in od], minlength=4)
+                extras["one_batch_drained"] = dict(nodes_per_s_all=B / td, certified_nodes_per_s=float(std[0] + std[3]) / td, seconds=td,
+                                                   note="the same 2048 warm-started nodes as one batch run to its last node; the headline streams K such batches (config.pipelined_batches)")
+            except Exception as ex:
+                extras["one_batch_drained"] = dict(error=repr(ex))
         if args.cpu_nodes > 0:
             extras["cpu_baseline"] = cpu_baseline_legs(A, mask, gamma, k, cfg["cut_type"], rho_scale, nodes[: args.cpu_nodes], args.depth)
     if rank == 0:
@@ -501,7 +511,7 @@ def main():
                        "jacobi_sweeps_last_step": info["jacobi_sweeps"], "instance_sha256": data.instance_sha256(A, mask)[:16]},
             "roofline": roofline, "cpu_baseline": extras.get("cpu_baseline"), "time_to_gap": extras.get("time_to_gap"),
             "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"), "branching_shor": extras.get("branching_shor"), "time_to_gap_config1": extras.get("time_to_gap_config1"),
-            "shor_config3": extras.get("shor_config3"), "cold_start": extras.get("cold_start"),
+            "shor_config3": extras.get("shor_config3"), "cold_start": extras.get("cold_start"), "one_batch_drained": extras.get("one_batch_drained"),
         }))
     eng.close()
     if dist.is_initialized():
