@@ -406,13 +406,21 @@ def main():
             Ab, maskb = data.branching_instance(seed=0)
             eb = omc_amd.Engine(Ab, maskb, gamma, 1, device=local)
             t1 = time.perf_counter()
-            solb, instb = bnb.branch_and_bound(eb, Ab, maskb, gap=1e-4, time_limit=60.0, batch=256, disjunctive_cuts_type="linear")
+            solb, instb = bnb.branch_and_bound(eb, Ab, maskb, gap=1e-4, time_limit=30.0, batch=256, disjunctive_cuts_type="linear")
             tb = time.perf_counter() - t1
             rd = instb["run_details"]
             extras["branching"] = dict(instance="100x100 rank-1 + 0.3 noise, 10% observed (data.branching_instance, seed 0)", sha256=data.instance_sha256(Ab, maskb)[:16],
                                        seconds=tb, gap=solb["gap"], lower_bound=solb["lower_bound"], upper_bound=solb["objective"], nodes_relaxed=rd["nodes_relax_feasible"],
                                        nodes_per_s=rd["nodes_relax_feasible"] / max(rd["solve_time_relaxation"], 1e-9), relaxation_seconds=rd["solve_time_relaxation"],
                                        altmin_seconds=rd["solve_time_altmin"], batch=256, reached_gap=bool(solb["gap"] <= 1e-4))
+            # the queue-driven driver on the same instance (one running solve fed by omc_relax_append / omc_relax_fetch_done / omc_relax_hold), same budget
+            t1 = time.perf_counter()
+            solq, instq = omc_amd.pkg.bnb_stream.branch_and_bound_streaming(eb, Ab, maskb, gap=1e-4, time_limit=30.0, slots=1024, disjunctive_cuts_type="linear")
+            rq = instq["run_details"]
+            extras["branching_streaming"] = dict(instance="the same instance, bnb_stream.branch_and_bound_streaming (nodes appended to one running solve as their parents finish)",
+                                                 seconds=time.perf_counter() - t1, gap=solq["gap"], lower_bound=solq["lower_bound"], upper_bound=solq["objective"],
+                                                 nodes_relaxed=rq["nodes_relax_feasible"], nodes_per_s=rq["nodes_relax_feasible"] / max(rq["solve_time_relaxation"], 1e-9),
+                                                 solves_staged=rq["epochs"], warm_started=rq["warm_started"], reached_gap=bool(solq["gap"] <= 1e-4))
             # the same instance with the reference's Shor valid inequalities (add_Shor_valid_inequalities = true, static list of the minors with all
             # four entries observed, OMC.jl:646-669): the Shor-mode relaxation closes it at the root
             t1 = time.perf_counter()
@@ -425,7 +433,7 @@ def main():
                                             nodes_relaxed=insts["run_details"]["nodes_relax_feasible"], reached_gap=bool(sols["gap"] <= 1e-4))
             eb.close()
         except Exception as ex:            # an extra must never cost the headline line
-            extras.setdefault("branching", dict(error=repr(ex))); extras.setdefault("branching_shor", dict(error=repr(ex)))
+            extras.setdefault("branching", dict(error=repr(ex))); extras.setdefault("branching_streaming", dict(error=repr(ex))); extras.setdefault("branching_shor", dict(error=repr(ex)))
         # ---- second half of the metric: wall-clock of the whole B&B (root altmin, penalty autotune, tree) to gap <= 1e-4 ---------
         tt = []
         for sd in (0, 1, 2):
@@ -510,7 +518,7 @@ def main():
                        "bounds_exchange": (comm_kind if use_comm else None),
                        "jacobi_sweeps_last_step": info["jacobi_sweeps"], "instance_sha256": data.instance_sha256(A, mask)[:16]},
             "roofline": roofline, "cpu_baseline": extras.get("cpu_baseline"), "time_to_gap": extras.get("time_to_gap"),
-            "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"), "branching_shor": extras.get("branching_shor"), "time_to_gap_config1": extras.get("time_to_gap_config1"),
+            "latency_b1": extras.get("latency_b1"), "branching": extras.get("branching"), "branching_shor": extras.get("branching_shor"), "branching_streaming": extras.get("branching_streaming"), "time_to_gap_config1": extras.get("time_to_gap_config1"),
             "shor_config3": extras.get("shor_config3"), "cold_start": extras.get("cold_start"), "one_batch_drained": extras.get("one_batch_drained"),
         }))
     eng.close()

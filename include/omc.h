@@ -165,9 +165,9 @@ int omc_relax_submit(omc_instance* h);
  * ones behind the staged ones in the order they were appended.  Not available in Shor mode. */
 /* omc_relax_fetch_done: results of the nodes finished since the last call, in the order they finished -- callable while the submitted solve is
  * running (the other half of a queue-driven host loop: OMC.jl:700-719 pops, relaxes and pushes the children of one node at a time).
- * node_ids[i] indexes the staged + appended nodes; per node: U (n*k), lambda_min (2), breakpoint_x (n) as in omc_relax_fetch (NULL: skipped). */
+ * node_ids[i] indexes the staged + appended nodes; per node: U (n*k), lambda_min (2), breakpoint_x (n), Y (n*n) as in omc_relax_fetch (NULL: skipped). */
 int omc_relax_fetch_done(omc_instance* h, int max_nodes, int* node_ids, double* objective, double* dual_bound, int* status, int* iters,
-                         double* U, double* lambda_min, double* breakpoint_x, int* n_out);
+                         double* U, double* lambda_min, double* breakpoint_x, double* Y, int* n_out);
 /* omc_relax_hold(h, 1) after staging: the submitted solve waits for omc_relax_append when it runs dry instead of ending (until omc_relax_hold(h, 0)
  * or the time limit of the parameters). */
 int omc_relax_hold(omc_instance* h, int on);

@@ -86,7 +86,7 @@ def load():
     lib.omc_left_singular_batch.argtypes = [vp, C.c_int, vp, vp]
     lib.omc_relax_reserve.argtypes = [vp, C.c_int, C.c_int]
     lib.omc_relax_hold.argtypes = [vp, C.c_int]
-    lib.omc_relax_fetch_done.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.omc_relax_fetch_done.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.omc_relax_append.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.omc_tuning_set.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.omc_tuning_reload_env.argtypes = [vp]

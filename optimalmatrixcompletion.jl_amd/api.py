@@ -113,7 +113,7 @@ class Engine:
         if A.ndim != 2 or A.shape != indices.shape:
             raise ValueError("Dimension mismatch.\nInput matrix A must have size (n, m);\nInput matrix indices must have size (n, m).")
         self.n, self.m = A.shape
-        self.k = int(k); self.gamma = float(gamma)
+        self.k = int(k); self.gamma = float(gamma); self.device = int(device)
         self.A = np.asfortranarray(A); self.indices = indices.astype(bool)
         self._lib = _lib.load()
         self._h = C.c_void_p()
@@ -245,17 +245,27 @@ class Engine:
         """Keep the submitted solve open when it runs dry (omc_relax_hold): it waits for append() until hold(False)."""
         _lib.check(self._lib.omc_relax_hold(self._h, 1 if on else 0))
 
-    def fetch_done(self, max_nodes=4096):
+    def fetch_done(self, max_nodes=4096, want_Y=False):
         """Results of the nodes finished since the last call (omc_relax_fetch_done), also while the submitted solve is running: a list of dicts
-        with the keys of fetch() that a driver needs to branch (node = index among the staged + appended nodes)."""
+        with the keys of fetch() that a driver needs to branch (node = index among the staged + appended nodes; Y on request)."""
         n, k = self.n, self.k
-        ids = np.zeros(max_nodes, np.int32); obj = np.zeros(max_nodes); lb = np.zeros(max_nodes); st = np.zeros(max_nodes, np.int32); it = np.zeros(max_nodes, np.int32)
-        U = np.zeros((max_nodes, n * k)); ev = np.zeros((max_nodes, 2)); bx = np.zeros((max_nodes, n)); cnt = np.zeros(1, np.int32)
+        key = (int(max_nodes), bool(want_Y))
+        if getattr(self, "_fd_key", None) != key:          # the receive buffers are kept between calls (a polling loop calls this every millisecond)
+            self._fd_key = key
+            self._fd = (np.zeros(max_nodes, np.int32), np.zeros(max_nodes), np.zeros(max_nodes), np.zeros(max_nodes, np.int32), np.zeros(max_nodes, np.int32),
+                        np.zeros((max_nodes, n * k)), np.zeros((max_nodes, 2)), np.zeros((max_nodes, n)), np.zeros(1, np.int32),
+                        np.zeros((max_nodes, n * n)) if want_Y else None)
+        ids, obj, lb, st, it, U, ev, bx, cnt, Y = self._fd
         _lib.check(self._lib.omc_relax_fetch_done(self._h, int(max_nodes), _lib.ptr(ids), _lib.ptr(obj), _lib.ptr(lb), _lib.ptr(st), _lib.ptr(it),
-                                                  _lib.ptr(U), _lib.ptr(ev), _lib.ptr(bx), _lib.ptr(cnt)))
-        return [dict(node=int(ids[i]), objective=float(obj[i]), dual_bound=float(lb[i]), status_code=int(st[i]), termination_status=STATUS_NAMES[int(st[i])],
+                                                  _lib.ptr(U), _lib.ptr(ev), _lib.ptr(bx), _lib.ptr(Y), _lib.ptr(cnt)))
+        out = []
+        for i in range(int(cnt[0])):
+            d = dict(node=int(ids[i]), objective=float(obj[i]), dual_bound=float(lb[i]), status_code=int(st[i]), termination_status=STATUS_NAMES[int(st[i])],
                      feasible=int(st[i]) != 3, iters=int(it[i]), U=U[i].reshape((n, k), order="F").copy(), lambda_min=ev[i].copy(), breakpoint_vec=bx[i].copy())
-                for i in range(int(cnt[0]))]
+            if want_Y:
+                d["Y"] = Y[i].reshape((n, n), order="F").copy()
+            out.append(d)
+        return out
 
     def solve(self):
         _lib.check(self._lib.omc_relax_solve(self._h))

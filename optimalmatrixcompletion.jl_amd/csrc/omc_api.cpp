@@ -506,8 +506,9 @@ int omc_relax_stage(omc_instance* h, int B, const omc_relax_params* params, int 
   OmcWS& w = h->ws;
   memset(&w, 0, sizeof(w));
   // continuous batching: S slots relax B nodes; a slot that finishes is harvested and re-used for the next pending node
-  int S = (P.slots > 0) ? std::min(P.slots, B) : std::min(B, 256);
-  if (h->tun.get("OMC_SLOTS")) S = std::max(1, std::min(B, atoi(h->tun.get("OMC_SLOTS"))));
+  const int Bcap = B + extra_nodes;      // with omc_relax_reserve the slots are sized for the nodes that may still come
+  int S = (P.slots > 0) ? std::min(P.slots, Bcap) : std::min(Bcap, 256);
+  if (h->tun.get("OMC_SLOTS")) S = std::max(1, std::min(Bcap, atoi(h->tun.get("OMC_SLOTS"))));
   h->Btot = B; h->Btot_live.store(B); h->node_cap = B + extra_nodes; h->staged_cut_type = cut_type; { std::lock_guard<std::mutex> lk(h->append_mu); h->append_closed = false; }
   { std::lock_guard<std::mutex> lk(h->done_mu); h->done_q.clear(); h->done_read = 0; }
   h->hold.store(0);
@@ -841,8 +842,8 @@ int omc_relax_solve(omc_instance* h) {
   struct CloseGuard { omc_instance* h; ~CloseGuard() { std::lock_guard<std::mutex> lk(h->append_mu); h->append_closed = true; h->ws.Btot = h->Btot_live.load(); h->Btot = h->ws.Btot; } } close_guard{h};
   // slot bookkeeping on the host: node of each slot (-1 = idle), next pending node
   std::vector<int> node_of(S), flags(3 * (size_t)S), done(S, 0);
-  for (int b = 0; b < S; ++b) node_of[b] = b;
-  int next = S, harvested = 0, nactive = S;
+  for (int b = 0; b < S; ++b) node_of[b] = (b < Btot) ? b : -1;      // with omc_relax_reserve there may be more slots than nodes staged so far: the others start idle
+  int next = std::min(S, Btot), harvested = 0, nactive = next;
   auto push_flags = [&](const std::vector<int>& init, const std::vector<int>& fin) -> int {
     for (int b = 0; b < S; ++b) { flags[b] = node_of[b] < 0 ? 0 : node_of[b]; flags[S + b] = init[b]; flags[2 * (size_t)S + b] = fin[b]; }
     HIPCHK(hipMemcpyAsync(w.node_of, flags.data(), sizeof(int) * flags.size(), hipMemcpyHostToDevice, s));
@@ -851,7 +852,9 @@ int omc_relax_solve(omc_instance* h) {
   };
   {
     std::vector<int> init(S, 1), fin(S, 0);
+    for (int b = 0; b < S; ++b) { init[b] = node_of[b] >= 0 ? 1 : 0; done[b] = node_of[b] >= 0 ? 0 : 1; }
     int rc = push_flags(init, fin); if (rc) return rc;
+    if (nactive < S) { HIPCHK(hipMemcpyAsync(w.done, done.data(), sizeof(int) * S, hipMemcpyHostToDevice, s)); HIPCHK(hipStreamSynchronize(s)); }      // idle slots are skipped by every kernel
   }
   const bool shor = h->shor_on;
   const ShWS& sw = h->sh;
@@ -891,7 +894,7 @@ int omc_relax_solve(omc_instance* h) {
     return 0;
   };
   { int rc = push_list(); if (rc) return rc; }
-  int gb0[2] = {0, 0}, gnB[2] = {S, 0}, gact[2] = {S, 0};
+  int gb0[2] = {0, 0}, gnB[2] = {S, 0}, gact[2] = {nactive, 0};
   if (G == 2) { gnB[0] = S / 2; gb0[1] = S / 2; gnB[1] = S - S / 2; gact[0] = gnB[0]; gact[1] = gnB[1]; }
   bool timed_out = false;
   h->total_sweeps = 0;
@@ -1257,9 +1260,9 @@ int omc_relax_hold(omc_instance* h, int on) {
 
 // Results of the nodes harvested since the last call, in harvest order -- also while the submitted solve is still running: with omc_relax_append
 // this is the other half of a queue-driven host loop (OMC.jl:700-719: pop, relax, push the children).  node_ids[i] indexes the staged + appended
-// nodes; U (n*k), lambda_min (2) and breakpoint_x (n) per node as in omc_relax_fetch (NULL: not copied).  *n_out = nodes returned (<= max_nodes).
+// nodes; U (n*k), lambda_min (2), breakpoint_x (n) and Y (n*n) per node as in omc_relax_fetch (NULL: not copied).  *n_out = nodes returned (<= max_nodes).
 int omc_relax_fetch_done(omc_instance* h, int max_nodes, int* node_ids, double* objective, double* dual_bound, int* status, int* iters,
-                         double* U, double* lambda_min, double* breakpoint_x, int* n_out) {
+                         double* U, double* lambda_min, double* breakpoint_x, double* Y, int* n_out) {
   if (!h || !h->staged || !node_ids || !n_out) return fail(OMC_ERR_ARGUMENT, "omc_relax_fetch_done: nothing staged or NULL argument");
   if (max_nodes < 0) return fail(OMC_ERR_ARGUMENT, "max_nodes is negative");
   HIPCHK(hipSetDevice(h->device));
@@ -1286,6 +1289,7 @@ int omc_relax_fetch_done(omc_instance* h, int max_nodes, int* node_ids, double* 
     if (U) HIPCHK(hipMemcpyAsync(U + i * n * k, w.oU + nb * n * k, 8 * n * k, hipMemcpyDeviceToHost, fs));
     if (lambda_min) HIPCHK(hipMemcpyAsync(lambda_min + 2 * i, w.olmin + 2 * nb, 16, hipMemcpyDeviceToHost, fs));
     if (breakpoint_x) HIPCHK(hipMemcpyAsync(breakpoint_x + i * n, w.obx + nb * n, 8 * n, hipMemcpyDeviceToHost, fs));
+    if (Y) HIPCHK(hipMemcpyAsync(Y + i * n * n, w.oY + nb * n * n, 8 * n * n, hipMemcpyDeviceToHost, fs));
   }
   HIPCHK(hipStreamSynchronize(fs));
   return 0;
@@ -1921,7 +1925,8 @@ int omc_altmin_master_objectives(omc_instance* h, int B, double* objective) {
   if (!h || !objective) return fail(OMC_ERR_ARGUMENT, "NULL argument");
   if (B <= 0 || B != h->amobj_B) return fail(OMC_ERR_ARGUMENT, "B does not match the last omc_altmin_batch call");
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipMemcpy(objective, h->amobj.p, 8 * (size_t)B, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpyAsync(objective, h->amobj.p, 8 * (size_t)B, hipMemcpyDeviceToHost, h->stream));      // never the legacy stream: another handle may be capturing a graph
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -2104,8 +2109,9 @@ int omc_violated_shor_minors(omc_instance* h, const double* X, int n_classes, co
     HIPCHK(hipStreamSynchronize(h->stream));
     if (got > cap || (long long)got < K) return fail(OMC_ERR_ARGUMENT, "internal: radix select emitted an unexpected number of keys");
     std::vector<uint64_t> ohi(got), olo(got);
-    HIPCHK(hipMemcpy(ohi.data(), h->sohi.p, got * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(olo.data(), h->solo.p, got * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(ohi.data(), h->sohi.p, got * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(olo.data(), h->solo.p, got * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<size_t> ord(got);
     for (size_t i = 0; i < got; ++i) ord[i] = i;
     std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return ohi[a] != ohi[b] ? ohi[a] > ohi[b] : olo[a] > olo[b]; });

@@ -1288,3 +1288,24 @@ def test_queue_driven_loop_append_and_fetch_done(have_gpu, omc):
         assert np.array_equal(o["U"], r["U"]) and np.array_equal(o["breakpoint_vec"], r["breakpoint_vec"])
     assert eng.fetch_done() == []
     eng.close()
+
+
+def test_streaming_branch_and_bound_against_the_round_based_driver(have_gpu, omc, orc):
+    """bnb_stream.branch_and_bound_streaming (one running solve fed through omc_relax_append / omc_relax_fetch_done / omc_relax_hold) against
+    bnb.branch_and_bound on an instance whose tree branches, the same time budget each: the two runs bracket the same optimum (each lower
+    bound below the other's incumbent), and the streaming run keeps the invariants of SURVEY 8c (LB monotone, LB <= UB, incumbent =
+    evaluate_objective of a rank-k X, counter identity) and warm-starts its nodes."""
+    A, mask = orc.make_instance(14, 18, 1, seed=5, kind="lowrank", n_indices=int(0.35 * 14 * 18), noise=0.15)
+    eng = omc.Engine(A, mask, GAMMA, 1)
+    a, ia = omc.pkg.bnb.branch_and_bound(eng, A, mask, gap=1e-4, time_limit=8.0, batch=64, rho_scale=8.0)
+    b, ib = omc.pkg.bnb_stream.branch_and_bound_streaming(eng, A, mask, gap=1e-4, time_limit=8.0, slots=64, rho_scale=8.0)
+    assert a["lower_bound"] <= b["objective"] * (1 + 1e-9) and b["lower_bound"] <= a["objective"] * (1 + 1e-9)
+    assert b["objective"] <= a["objective"] * (1 + 0.05)                      # the same altmin schedule finds a comparable incumbent
+    c = ib["run_details"]; log = np.array(ib["run_log"])
+    assert c["nodes_relax_infeasible"] + c["nodes_relax_feasible"] == c["nodes_explored"] and c["nodes_explored"] > 50
+    assert (np.diff(log[:, 3]) >= -1e-9).all() and b["lower_bound"] <= b["objective"] * (1 + 1e-9)
+    assert np.linalg.matrix_rank(b["X"], tol=1e-8) <= 1
+    assert b["objective"] == pytest.approx(orc.evaluate_objective(b["X"], A, mask, GAMMA), rel=1e-10)
+    assert c["warm_started"] > 0.5 * c["nodes_explored"]
+    print("round-based:", ia["run_details"]["nodes_explored"], "nodes, lb", a["lower_bound"], "ub", a["objective"], "; streaming:", c["nodes_explored"], "nodes, lb", b["lower_bound"], "ub", b["objective"], "epochs", c["epochs"], "warm", c["warm_started"])
+    eng.close()
