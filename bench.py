@@ -52,6 +52,8 @@ def parse():
                     "2: the same, but batches 2..K are appended to the RUNNING solve of batch 1 (omc_relax_reserve / omc_relax_append), descriptors uploaded inside the timed region; "
                     "0: each step is staged, solved and drained on its own (rounds 1-2)")
     ap.add_argument("--early-stop", type=float, default=None, help="early_stop_factor of the relaxation parameters (library default 1.5; 0 = rule off)")
+    ap.add_argument("--child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-arg", default="{}", help=argparse.SUPPRESS)
     ap.add_argument("--extras", type=int, default=1, help="0: skip latency_b1 / branching / time_to_gap / cpu_baseline (rank 0, N=1 only)")
     return ap.parse_args()
 
@@ -119,6 +121,48 @@ def cpu_baseline_legs(A, mask, gamma, k, cut_type, rho_scale, nodes, depth):
                 numpy_port=dict(value=len(nodes[:2]) / t_np, cores=1, sample=f"first {len(nodes[:2])} nodes, numpy / LAPACK oracle pinned to one thread (threadpoolctl); iterations {its_np}"))
 
 
+def branching_extras(gamma, local):
+    """The three runs on the instance whose tree really branches (round-based driver, queue-driven driver, Shor valid inequalities): run in a child
+    process of bench.py (--child branching), so that nothing in these minute-long driver runs can cost the headline line."""
+    import omc_amd
+    bnb, data = omc_amd.pkg.bnb, omc_amd.pkg.data
+    extras = {}
+    # ---- an instance whose tree really branches (config 2's own tree closes at the root) ------------------------------------------
+    try:
+        Ab, maskb = data.branching_instance(seed=0)
+        eb = omc_amd.Engine(Ab, maskb, gamma, 1, device=local)
+        t1 = time.perf_counter()
+        solb, instb = bnb.branch_and_bound(eb, Ab, maskb, gap=1e-4, time_limit=30.0, batch=256, disjunctive_cuts_type="linear")
+        tb = time.perf_counter() - t1
+        rd = instb["run_details"]
+        extras["branching"] = dict(instance="100x100 rank-1 + 0.3 noise, 10% observed (data.branching_instance, seed 0)", sha256=data.instance_sha256(Ab, maskb)[:16],
+                                   seconds=tb, gap=solb["gap"], lower_bound=solb["lower_bound"], upper_bound=solb["objective"], nodes_relaxed=rd["nodes_relax_feasible"],
+                                   nodes_per_s=rd["nodes_relax_feasible"] / max(rd["solve_time_relaxation"], 1e-9), relaxation_seconds=rd["solve_time_relaxation"],
+                                   altmin_seconds=rd["solve_time_altmin"], batch=256, reached_gap=bool(solb["gap"] <= 1e-4))
+        # the queue-driven driver on the same instance (one running solve fed by omc_relax_append / omc_relax_fetch_done / omc_relax_hold), same budget
+        t1 = time.perf_counter()
+        solq, instq = omc_amd.pkg.bnb_stream.branch_and_bound_streaming(eb, Ab, maskb, gap=1e-4, time_limit=30.0, slots=1024, disjunctive_cuts_type="linear")
+        rq = instq["run_details"]
+        extras["branching_streaming"] = dict(instance="the same instance, bnb_stream.branch_and_bound_streaming (nodes appended to one running solve as their parents finish)",
+                                             seconds=time.perf_counter() - t1, gap=solq["gap"], lower_bound=solq["lower_bound"], upper_bound=solq["objective"],
+                                             nodes_relaxed=rq["nodes_relax_feasible"], nodes_per_s=rq["nodes_relax_feasible"] / max(rq["solve_time_relaxation"], 1e-9),
+                                             solves_staged=rq["epochs"], warm_started=rq["warm_started"], reached_gap=bool(solq["gap"] <= 1e-4))
+        # the same instance with the reference's Shor valid inequalities (add_Shor_valid_inequalities = true, static list of the minors with all
+        # four entries observed, OMC.jl:646-669): the Shor-mode relaxation closes it at the root
+        t1 = time.perf_counter()
+        sols, insts = bnb.branch_and_bound(eb, Ab, maskb, gap=1e-4, time_limit=60.0, batch=32, disjunctive_cuts_type="linear", add_Shor_valid_inequalities=True,
+                                           Shor_valid_inequalities_noisy_rank1_num_entries_present=(4,),
+                                           shor_params=omc_amd.default_params(rho_scale=1.0, eps_gap=1e-5, max_iters=6000, time_limit=30.0))
+        ts = time.perf_counter() - t1
+        extras["branching_shor"] = dict(instance="the same instance, add_Shor_valid_inequalities = true, minors with four observed entries (static list)",
+                                        seconds_to_gap=ts, gap=sols["gap"], lower_bound=sols["lower_bound"], upper_bound=sols["objective"],
+                                        nodes_relaxed=insts["run_details"]["nodes_relax_feasible"], reached_gap=bool(sols["gap"] <= 1e-4))
+        eb.close()
+    except Exception as ex:            # an extra must never cost the headline line
+        extras.setdefault("branching", dict(error=repr(ex))); extras.setdefault("branching_streaming", dict(error=repr(ex))); extras.setdefault("branching_shor", dict(error=repr(ex)))
+    return extras
+
+
 def _cpu_share(nproc):
     """Cores this process may really use: the scheduler affinity mask and the cgroup CPU quota (a GPU box of this pool exposes 256 logical CPUs
     and grants a share of them per GPU)."""
@@ -166,6 +210,12 @@ def _cpu_worker(job):
 
 def main():
     args = parse()
+    os.environ.setdefault("OMC_SEGV_TRACE", "1")      # a fatal signal inside the library prints its native frames to stderr before the process dies
+    if args.child == "branching":
+        sys.path.insert(0, ROOT)
+        ca = json.loads(args.child_arg)
+        print(json.dumps(branching_extras(float(ca.get("gamma", 80.0)), int(ca.get("local", 0)))), flush=True)
+        return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         spawn_ranks(args)
@@ -401,39 +451,20 @@ def main():
         e1.close()
         extras["latency_b1"] = dict(value=len(sample) / tl, unit="node-relaxations/s", nodes=len(sample), ms_per_node=tl / len(sample) * 1e3,
                                     iters_mean=float(np.mean(its1)), us_per_iteration=tl / max(1, sum(its1)) * 1e6)
-        # ---- an instance whose tree really branches (config 2's own tree closes at the root) ------------------------------------------
+        # ---- an instance whose tree really branches (config 2's own tree closes at the root): three driver runs, in a child process ------------
         try:
-            Ab, maskb = data.branching_instance(seed=0)
-            eb = omc_amd.Engine(Ab, maskb, gamma, 1, device=local)
-            t1 = time.perf_counter()
-            solb, instb = bnb.branch_and_bound(eb, Ab, maskb, gap=1e-4, time_limit=30.0, batch=256, disjunctive_cuts_type="linear")
-            tb = time.perf_counter() - t1
-            rd = instb["run_details"]
-            extras["branching"] = dict(instance="100x100 rank-1 + 0.3 noise, 10% observed (data.branching_instance, seed 0)", sha256=data.instance_sha256(Ab, maskb)[:16],
-                                       seconds=tb, gap=solb["gap"], lower_bound=solb["lower_bound"], upper_bound=solb["objective"], nodes_relaxed=rd["nodes_relax_feasible"],
-                                       nodes_per_s=rd["nodes_relax_feasible"] / max(rd["solve_time_relaxation"], 1e-9), relaxation_seconds=rd["solve_time_relaxation"],
-                                       altmin_seconds=rd["solve_time_altmin"], batch=256, reached_gap=bool(solb["gap"] <= 1e-4))
-            # the queue-driven driver on the same instance (one running solve fed by omc_relax_append / omc_relax_fetch_done / omc_relax_hold), same budget
-            t1 = time.perf_counter()
-            solq, instq = omc_amd.pkg.bnb_stream.branch_and_bound_streaming(eb, Ab, maskb, gap=1e-4, time_limit=30.0, slots=1024, disjunctive_cuts_type="linear")
-            rq = instq["run_details"]
-            extras["branching_streaming"] = dict(instance="the same instance, bnb_stream.branch_and_bound_streaming (nodes appended to one running solve as their parents finish)",
-                                                 seconds=time.perf_counter() - t1, gap=solq["gap"], lower_bound=solq["lower_bound"], upper_bound=solq["objective"],
-                                                 nodes_relaxed=rq["nodes_relax_feasible"], nodes_per_s=rq["nodes_relax_feasible"] / max(rq["solve_time_relaxation"], 1e-9),
-                                                 solves_staged=rq["epochs"], warm_started=rq["warm_started"], reached_gap=bool(solq["gap"] <= 1e-4))
-            # the same instance with the reference's Shor valid inequalities (add_Shor_valid_inequalities = true, static list of the minors with all
-            # four entries observed, OMC.jl:646-669): the Shor-mode relaxation closes it at the root
-            t1 = time.perf_counter()
-            sols, insts = bnb.branch_and_bound(eb, Ab, maskb, gap=1e-4, time_limit=60.0, batch=32, disjunctive_cuts_type="linear", add_Shor_valid_inequalities=True,
-                                               Shor_valid_inequalities_noisy_rank1_num_entries_present=(4,),
-                                               shor_params=omc_amd.default_params(rho_scale=1.0, eps_gap=1e-5, max_iters=6000, time_limit=30.0))
-            ts = time.perf_counter() - t1
-            extras["branching_shor"] = dict(instance="the same instance, add_Shor_valid_inequalities = true, minors with four observed entries (static list)",
-                                            seconds_to_gap=ts, gap=sols["gap"], lower_bound=sols["lower_bound"], upper_bound=sols["objective"],
-                                            nodes_relaxed=insts["run_details"]["nodes_relax_feasible"], reached_gap=bool(sols["gap"] <= 1e-4))
-            eb.close()
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "branching", "--child-arg", json.dumps(dict(gamma=gamma, local=local))],
+                                capture_output=True, text=True, timeout=400)
+            line = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+            if cp.returncode == 0 and line:
+                extras.update(json.loads(line[-1]))
+            else:
+                err = dict(error=f"child exited with {cp.returncode}", stderr_tail=cp.stderr[-1500:])
+                for key in ("branching", "branching_streaming", "branching_shor"):
+                    extras[key] = err
         except Exception as ex:            # an extra must never cost the headline line
-            extras.setdefault("branching", dict(error=repr(ex))); extras.setdefault("branching_streaming", dict(error=repr(ex))); extras.setdefault("branching_shor", dict(error=repr(ex)))
+            for key in ("branching", "branching_streaming", "branching_shor"):
+                extras[key] = dict(error=repr(ex))
         # ---- second half of the metric: wall-clock of the whole B&B (root altmin, penalty autotune, tree) to gap <= 1e-4 ---------
         tt = []
         for sd in (0, 1, 2):

@@ -28,6 +28,9 @@
 #include "omc_shor_relax.h"
 #include <unordered_map>
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types only: the library is loaded with dlopen on first use, so that libomc_hip.so has no hard dependency on it
 
 static thread_local std::string g_err;
@@ -84,6 +87,7 @@ static const char* const OMC_TUNING_KEYS[] = {
   "OMC_NO_WARMSTART",
   "OMC_NO_WS_SPLIT",
   "OMC_NO_YX",
+  "OMC_SEGV_TRACE",
   "OMC_REFILL_EVERY",
   "OMC_SHOR_DEBUG",
   "OMC_SHOR_EXPLICIT",
@@ -104,6 +108,16 @@ struct Tuning {
   std::unordered_map<std::string, std::string> kv;
   const char* get(const char* name) const { auto it = kv.find(name); return it == kv.end() ? nullptr : it->second.c_str(); }
 };
+// diagnostics (OMC_SEGV_TRACE=1 at instance creation): print the native frames of a crashing thread before the default action runs
+static void omc_segv_trace(int sig) {
+  void* fr[64];
+  const int nf = backtrace(fr, 64);
+  const char msg[] = "libomc_hip: fatal signal, native frames:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(fr, nf, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
 static void tuning_from_env(Tuning& t) {
   t.kv.clear();
   for (const char* key : OMC_TUNING_KEYS) if (const char* v = getenv(key)) t.kv[key] = v;
@@ -211,6 +225,7 @@ int omc_instance_create(int n, int m, int k, const double* A, const uint8_t* mas
   HIPCHK(hipSetDevice(device));
   omc_instance* h = new omc_instance();
   tuning_from_env(h->tun);
+  if (h->tun.get("OMC_SEGV_TRACE")) { signal(SIGSEGV, omc_segv_trace); signal(SIGABRT, omc_segv_trace); }
   struct Guard { omc_instance*& p; ~Guard() { if (p) omc_instance_destroy(p); } } guard{h};     // every early return below frees the handle
   h->n = n; h->m = m; h->k = k; h->gamma = gamma; h->device = device;
   h->A.assign(A, A + (size_t)n * m);
