@@ -136,6 +136,7 @@ struct omc_instance {
   Tuning tun;
   hipStream_t gs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   hipEvent_t gev[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+  hipEvent_t gevc[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};      // the same fork / join events for bodies recorded under stream capture: an event is never used both inside a captured graph and eagerly
   hipEvent_t ev_main = nullptr;
   DevBuf dA, dmask, dcol_ptr, dcol_idx, dcol_val, dNcnt, dwY, dsolo, dwide;
   int nwide = 0;      // columns outside the pairs with at most 64 observed rows (k_colprox_wide)
@@ -322,7 +323,7 @@ void omc_instance_destroy(omc_instance* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (int g = 0; g < 2; ++g) {
     for (int q = 0; q < 4; ++q) if (h->gs[g][q]) (void)hipStreamDestroy(h->gs[g][q]);
-    for (int q = 0; q < 5; ++q) if (h->gev[g][q]) (void)hipEventDestroy(h->gev[g][q]);
+    for (int q = 0; q < 5; ++q) { if (h->gev[g][q]) (void)hipEventDestroy(h->gev[g][q]); if (h->gevc[g][q]) (void)hipEventDestroy(h->gevc[g][q]); }
   }
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   if (h->append_stream) (void)hipStreamDestroy(h->append_stream);
@@ -889,7 +890,7 @@ int omc_relax_solve(omc_instance* h) {
   if (multi && !h->ev_main) {
     for (int g = 0; g < 2; ++g) {
       for (int q = 0; q < 4; ++q) HIPCHK(hipStreamCreateWithFlags(&h->gs[g][q], hipStreamNonBlocking));
-      for (int q = 0; q < 5; ++q) HIPCHK(hipEventCreateWithFlags(&h->gev[g][q], hipEventDisableTiming));
+      for (int q = 0; q < 5; ++q) { HIPCHK(hipEventCreateWithFlags(&h->gev[g][q], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->gevc[g][q], hipEventDisableTiming)); }
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
   }
@@ -918,16 +919,20 @@ int omc_relax_solve(omc_instance* h) {
   // the body of an iteration (fork, three concurrent blocks, join, global step) is captured once into a hipGraph and replayed; it is
   // captured again only when the number of live slots changes.  Per-kernel HIP-event timing is not available inside a graph, so the
   // large batches that the bench times keep the eager path.
-  const int graph_max = h->tun.get("OMC_GRAPH_MAX") ? atoi(h->tun.get("OMC_GRAPH_MAX")) : 16;      // measured: -6 % per iteration at batch 1, +8 % at 128 slots of order 200
+  // hipGraph replay of the iteration body for small batches (measured: -6 % per iteration at batch 1, +8 % at 128 slots of order 200) is OPT-IN since
+  // the end of round 3 (OMC_GRAPH_MAX=16): a sporadic host crash inside omc_relax_solve was seen three times in the round, every time with few live
+  // slots -- i.e. on this path -- and never with it off; not located
+  const int graph_max = h->tun.get("OMC_GRAPH_MAX") ? atoi(h->tun.get("OMC_GRAPH_MAX")) : 0;
   const bool no_graph = h->tun.get("OMC_NO_GRAPH") != nullptr;      // read once per solve, not per iteration
   const int timing_stride = h->tun.get("OMC_TIMING_STRIDE") ? atoi(h->tun.get("OMC_TIMING_STRIDE")) : 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr}; int gexec_n = -1;
   struct GraphGuard { hipGraphExec_t* e; ~GraphGuard() { for (int q = 0; q < 2; ++q) if (e[q]) (void)hipGraphExecDestroy(e[q]); } } gguard{gexec};
-  auto body = [&](int g, const OmcWS& wg, bool timed, bool with_aa) -> int {
+  auto body = [&](int g, const OmcWS& wg, bool timed, bool with_aa, bool capturing) -> int {
+    hipEvent_t* const ev = capturing ? h->gevc[g] : h->gev[g];
     hipStream_t sm = multi ? h->gs[g][0] : s, sb = multi ? h->gs[g][1] : s, sc = multi ? h->gs[g][2] : s;
     if (multi) {
-      HIPCHK(hipEventRecord(h->gev[g][0], sm));
-      HIPCHK(hipStreamWaitEvent(sb, h->gev[g][0], 0)); HIPCHK(hipStreamWaitEvent(sc, h->gev[g][0], 0));
+      HIPCHK(hipEventRecord(ev[0], sm));
+      HIPCHK(hipStreamWaitEvent(sb, ev[0], 0)); HIPCHK(hipStreamWaitEvent(sc, ev[0], 0));
     }
 #define MAYBE_TIMED(strm, cls, units_, call) do { if (timed) TIMED_ON(strm, cls, units_, call); else { call; } } while (0)
     // the cone workgroups are few (two per CU, long serial phases) and the column waves many: the cone kernel goes first so that its
@@ -946,8 +951,8 @@ int omc_relax_solve(omc_instance* h) {
       MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
       MAYBE_TIMED(sc, OMC_KERNEL_SHOR_MINORS, gact[g], { omc_shor_launch_minor_pre(&sw, sc); omc_shor_launch_vkeys(&sw, sc); });
       if (multi) {
-        HIPCHK(hipEventRecord(h->gev[g][1], sb)); HIPCHK(hipEventRecord(h->gev[g][2], sc));
-        HIPCHK(hipStreamWaitEvent(sm, h->gev[g][1], 0)); HIPCHK(hipStreamWaitEvent(sm, h->gev[g][2], 0));
+        HIPCHK(hipEventRecord(ev[1], sb)); HIPCHK(hipEventRecord(ev[2], sc));
+        HIPCHK(hipStreamWaitEvent(sm, ev[1], 0)); HIPCHK(hipStreamWaitEvent(sm, ev[2], 0));
       }
       MAYBE_TIMED(sm, OMC_KERNEL_GLOBAL, gact[g], omc_launch_global(&wg, h->glob_use_lds, h->glob_lds, sm));
       MAYBE_TIMED(sm, OMC_KERNEL_SHOR_COLS, gact[g], omc_shor_launch_cols(&sw, sm));
@@ -963,13 +968,13 @@ int omc_relax_solve(omc_instance* h) {
       MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
       OmcWS wA = wg; wA.ws_phase = 1;
       MAYBE_TIMED(sc, OMC_KERNEL_CONE, gact[g], omc_launch_cone_ws(&wA, h->ws_lpp, h->ws_use_lds, h->ws_lds, sc));
-      HIPCHK(hipEventRecord(h->gev[g][4], sc));
+      HIPCHK(hipEventRecord(ev[4], sc));
     }
     if (colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
     if (w.sub_enable) MAYBE_TIMED(sm, OMC_KERNEL_CONESUB, gact[g], omc_launch_cone_sub(&wg, sm));
     if (!colprox_first) MAYBE_TIMED(sb, OMC_KERNEL_COLPROX, (int64_t)gact[g] * w.m, omc_launch_colprox(&wg, 0, sb));
     if (split) {
-      HIPCHK(hipStreamWaitEvent(sm, h->gev[g][4], 0));
+      HIPCHK(hipStreamWaitEvent(sm, ev[4], 0));
       OmcWS wB = wg; wB.ws_phase = 2;
       MAYBE_TIMED(sm, OMC_KERNEL_CONE, 0, omc_launch_cone_ws(&wB, h->ws_lpp, h->ws_use_lds, h->ws_lds, sm));
     }
@@ -977,8 +982,8 @@ int omc_relax_solve(omc_instance* h) {
     else MAYBE_TIMED(sm, OMC_KERNEL_CONE, gact[g], omc_launch_cone(&wg, CONE_CLIP01, h->cone_use_lds, h->cone_lds, sm));
     if (!split) MAYBE_TIMED(sc, OMC_KERNEL_SMALL, gact[g], omc_launch_small(&wg, SMALL_PROJ, h->small_use_lds, h->small_lds, sc));
     if (multi) {
-      HIPCHK(hipEventRecord(h->gev[g][1], sb)); HIPCHK(hipEventRecord(h->gev[g][2], sc));
-      HIPCHK(hipStreamWaitEvent(sm, h->gev[g][1], 0)); HIPCHK(hipStreamWaitEvent(sm, h->gev[g][2], 0));
+      HIPCHK(hipEventRecord(ev[1], sb)); HIPCHK(hipEventRecord(ev[2], sc));
+      HIPCHK(hipStreamWaitEvent(sm, ev[1], 0)); HIPCHK(hipStreamWaitEvent(sm, ev[2], 0));
     }
     MAYBE_TIMED(sm, OMC_KERNEL_GLOBAL, gact[g], omc_launch_global(&wg, h->glob_use_lds, h->glob_lds, sm));
     if (with_aa) MAYBE_TIMED(sm, OMC_KERNEL_ACCEL, gact[g], omc_launch_aa(&wg, sm));
@@ -1041,7 +1046,7 @@ int omc_relax_solve(omc_instance* h) {
           for (int q = 0; q < (w.accel ? 2 : 1); ++q) {
             hipGraph_t gr = nullptr;
             HIPCHK(hipStreamBeginCapture(sm, hipStreamCaptureModeThreadLocal));
-            int rc = body(g, wg, false, q == 1);
+            int rc = body(g, wg, false, q == 1, true);
             hipError_t ce = hipStreamEndCapture(sm, &gr);
             if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
             HIPCHK(ce);
@@ -1055,7 +1060,7 @@ int omc_relax_solve(omc_instance* h) {
         HIPCHK(hipGraphLaunch(gexec[q], sm));
         h->launches[OMC_KERNEL_GLOBAL] += 1; h->units[OMC_KERNEL_GLOBAL] += gact[g];
       } else {
-        int rc = body(g, wg, sampled, !is_check && w.accel); if (rc) return rc;
+        int rc = body(g, wg, sampled, !is_check && w.accel, false); if (rc) return rc;
       }
       if (multi && is_check) { HIPCHK(hipEventRecord(h->gev[g][3], sm)); HIPCHK(hipStreamWaitEvent(s, h->gev[g][3], 0)); }
     }
