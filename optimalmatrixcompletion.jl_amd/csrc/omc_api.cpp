@@ -76,6 +76,7 @@ static const char* const OMC_TUNING_KEYS[] = {
   "OMC_DENSE_CHECK",
   "OMC_GLOBAL_NOLDS",
   "OMC_GRAPH_MAX",
+  "OMC_GRAPH_TAILS",
   "OMC_GROUPS",
   "OMC_JACOBI_TAU",
   "OMC_NO_COLPROX_PAIR",
@@ -919,10 +920,12 @@ int omc_relax_solve(omc_instance* h) {
   // the body of an iteration (fork, three concurrent blocks, join, global step) is captured once into a hipGraph and replayed; it is
   // captured again only when the number of live slots changes.  Per-kernel HIP-event timing is not available inside a graph, so the
   // large batches that the bench times keep the eager path.
-  // hipGraph replay of the iteration body for small batches (measured: -6 % per iteration at batch 1, +8 % at 128 slots of order 200) is OPT-IN since
-  // the end of round 3 (OMC_GRAPH_MAX=16): a sporadic host crash inside omc_relax_solve was seen three times in the round, every time with few live
-  // slots -- i.e. on this path -- and never with it off; not located
-  const int graph_max = h->tun.get("OMC_GRAPH_MAX") ? atoi(h->tun.get("OMC_GRAPH_MAX")) : 0;
+  // hipGraph replay of the iteration body for small batches (measured at batch 1: 266 instead of 322 us per iteration).  Since the end of round 3
+  // only for batches that are small FROM THE START (<= OMC_GRAPH_MAX = 16 nodes staged: one capture per solve): the draining tail of a large batch
+  // re-captured the graph at every harvest, and a sporadic host crash inside omc_relax_solve was seen three times in the round, always in or after
+  // solves on that path, never with replay off; not located.  OMC_GRAPH_TAILS=1 restores replay in the tails.
+  const int graph_max_cfg = h->tun.get("OMC_GRAPH_MAX") ? atoi(h->tun.get("OMC_GRAPH_MAX")) : 16;
+  const int graph_max = (Btot <= graph_max_cfg || h->tun.get("OMC_GRAPH_TAILS")) ? graph_max_cfg : 0;
   const bool no_graph = h->tun.get("OMC_NO_GRAPH") != nullptr;      // read once per solve, not per iteration
   const int timing_stride = h->tun.get("OMC_TIMING_STRIDE") ? atoi(h->tun.get("OMC_TIMING_STRIDE")) : 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr}; int gexec_n = -1;
