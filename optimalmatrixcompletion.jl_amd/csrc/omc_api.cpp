@@ -77,6 +77,7 @@ static const char* const OMC_TUNING_KEYS[] = {
   "OMC_GLOBAL_NOLDS",
   "OMC_GRAPH_MAX",
   "OMC_GRAPH_TAILS",
+  "OMC_GRAPH_SHARED_EVENTS",
   "OMC_GROUPS",
   "OMC_JACOBI_TAU",
   "OMC_NO_COLPROX_PAIR",
@@ -926,12 +927,13 @@ int omc_relax_solve(omc_instance* h) {
   // solves on that path, never with replay off; not located.  OMC_GRAPH_TAILS=1 restores replay in the tails.
   const int graph_max_cfg = h->tun.get("OMC_GRAPH_MAX") ? atoi(h->tun.get("OMC_GRAPH_MAX")) : 16;
   const int graph_max = (Btot <= graph_max_cfg || h->tun.get("OMC_GRAPH_TAILS")) ? graph_max_cfg : 0;
+  const bool shared_events = h->tun.get("OMC_GRAPH_SHARED_EVENTS") != nullptr;      // diagnostics: the pre-fix behaviour (captured and eager bodies use the same fork / join events)
   const bool no_graph = h->tun.get("OMC_NO_GRAPH") != nullptr;      // read once per solve, not per iteration
   const int timing_stride = h->tun.get("OMC_TIMING_STRIDE") ? atoi(h->tun.get("OMC_TIMING_STRIDE")) : 1;
   hipGraphExec_t gexec[2] = {nullptr, nullptr}; int gexec_n = -1;
   struct GraphGuard { hipGraphExec_t* e; ~GraphGuard() { for (int q = 0; q < 2; ++q) if (e[q]) (void)hipGraphExecDestroy(e[q]); } } gguard{gexec};
   auto body = [&](int g, const OmcWS& wg, bool timed, bool with_aa, bool capturing) -> int {
-    hipEvent_t* const ev = capturing ? h->gevc[g] : h->gev[g];
+    hipEvent_t* const ev = (capturing && !shared_events) ? h->gevc[g] : h->gev[g];
     hipStream_t sm = multi ? h->gs[g][0] : s, sb = multi ? h->gs[g][1] : s, sc = multi ? h->gs[g][2] : s;
     if (multi) {
       HIPCHK(hipEventRecord(ev[0], sm));
